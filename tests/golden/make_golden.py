@@ -1,0 +1,358 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ from the LIVE reference.
+
+Runs only in the authoring container (the reference never travels):
+
+    python tests/golden/make_golden.py
+
+It imports /root/reference unchanged as a package called ``tetris`` through a
+symlink in a temp dir (the sources do ``from tetris import ...``:
+game.py:3-5, tetromino.py:2) and records inputs + expected outputs as small
+.npz files.  Fixtures are data only -- no reference source is stored.
+
+Fixture families:
+  g1_placements_*   every placement of all 9 pieces on random/edge boards
+  g2_traj_*         seeded trajectories through game.Tetris (step outputs,
+                    boards, piece stream incl. bag-across-reset behaviour,
+                    get_after_states matrices)
+  g3_rng            np.random.permutation bags for seeds 0..15
+  g4_edges          hand-built edge cases
+  g5_dtypes         observation dtypes with / without feature_directions
+"""
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference"
+
+CATALOGUE = ["Straight", "Square", "SnakeR", "ThreeLine", "ThreeL", "SnakeL", "T", "RCorner", "LCorner"]
+STANDARD7 = ["Straight", "RCorner", "LCorner", "Square", "SnakeR", "SnakeL", "T"]  # game.py:41-47
+
+
+def import_reference():
+    os.environ.setdefault("MPLBACKEND", "Agg")
+    sys.dont_write_bytecode = True
+    tmp = tempfile.mkdtemp(prefix="tetris_ref_")
+    os.symlink(REF, os.path.join(tmp, "tetris"))
+    sys.path.insert(0, tmp)
+    from tetris import game, state, tetromino  # noqa
+    return game, state, tetromino
+
+
+def cols_of(rep):
+    rep = np.asarray(rep).astype(np.uint64)
+    w = (np.uint64(1) << np.arange(rep.shape[0], dtype=np.uint64))[:, None]
+    return (rep * w).sum(axis=0).astype(np.uint64)
+
+
+def random_board(rng, R, C, kind):
+    """A legal (non-terminal, heights-consistent) board: rows [0, R) only."""
+    rows = R + 4
+    rep = np.zeros((rows, C), dtype=np.int_)
+    if kind == "empty":
+        return rep
+    if kind == "low":
+        hmax = max(2, R // 3)
+    elif kind == "mid":
+        hmax = max(3, (2 * R) // 3)
+    else:  # high / nearfull / tall
+        hmax = R
+    heights = rng.integers(0, hmax + 1, size=C)
+    if kind == "tall":
+        heights = rng.integers(max(0, R - 4), R + 1, size=C)
+    if kind == "maxheight":
+        heights = np.full(C, R)
+        heights[rng.integers(0, C)] = rng.integers(0, R)
+    hole_p = rng.choice([0.0, 0.1, 0.3])
+    for c in range(C):
+        h = int(heights[c])
+        if h == 0:
+            continue
+        col = (rng.random(h) >= hole_p).astype(np.int_)
+        col[h - 1] = 1
+        rep[:h, c] = col
+    if kind in ("nearfull", "tall", "maxheight"):
+        # make some rows full except 1-4 adjacent columns so clears happen
+        for _ in range(rng.integers(1, 5)):
+            r = int(rng.integers(0, max(1, int(heights.max()))))
+            w = int(rng.integers(1, 5))
+            c0 = int(rng.integers(0, C - w + 1))
+            rep[r, :] = 1
+            rep[r, c0:c0 + w] = 0
+        # repair heights consistency: nothing to do, heights are recomputed
+    # no row may be completely full in a reachable state
+    for r in range(rows):
+        if rep[r].sum() == C:
+            rep[r, rng.integers(0, C)] = 0
+    rep[R:, :] = 0
+    return rep
+
+
+def gen_placements(game, state, tetromino, R, C, n_boards, seed):
+    rng = np.random.default_rng(seed)
+    kinds = ["empty", "low", "mid", "high", "nearfull", "tall", "maxheight"]
+    pieces = [getattr(tetromino, n)("bcts", 8, C) for n in CATALOGUE]
+    boards, rec = [], {k: [] for k in (
+        "board_ix", "piece", "cols", "heights", "n_cleared", "terminal", "anchor_row", "anchor_col", "feats")}
+    for b in range(n_boards):
+        kind = kinds[b % len(kinds)]
+        rep = random_board(rng, R, C, kind)
+        st = state.State(representation=rep.copy(), lowest_free_rows=None)
+        assert not st.terminal_state
+        boards.append(cols_of(st.representation))
+        for pi, piece in enumerate(pieces):
+            for child in piece.get_after_states(st):
+                rec["board_ix"].append(b)
+                rec["piece"].append(pi)
+                rec["cols"].append(cols_of(child.representation))
+                rec["heights"].append(np.asarray(child.lowest_free_rows, dtype=np.int16))
+                rec["n_cleared"].append(child.n_cleared_lines)
+                rec["terminal"].append(int(child.terminal_state))
+                rec["anchor_row"].append(int(child.anchor_row))
+                rec["anchor_col"].append(int(child.anchor_col))
+                f = child.get_features()
+                assert f.dtype == np.float32
+                rec["feats"].append(f.copy())
+    out = dict(R=R, C=C, boards=np.array(boards, dtype=np.uint64))
+    out["board_ix"] = np.array(rec["board_ix"], np.int32)
+    out["piece"] = np.array(rec["piece"], np.int8)
+    out["cols"] = np.array(rec["cols"], np.uint64)
+    out["heights"] = np.array(rec["heights"], np.int16)
+    out["n_cleared"] = np.array(rec["n_cleared"], np.int8)
+    out["terminal"] = np.array(rec["terminal"], np.int8)
+    out["anchor_row"] = np.array(rec["anchor_row"], np.int16)
+    out["anchor_col"] = np.array(rec["anchor_col"], np.int16)
+    out["feats"] = np.array(rec["feats"], np.float32)
+    return out
+
+
+def make_env(game, tetromino, C, R, piece_names, seed, feature_directions=None):
+    np.random.seed(seed)  # the reference bag uses the global legacy stream
+    env = game.Tetris(C, R, feature_directions=feature_directions)
+    if piece_names is not None:
+        # game.py:38-47: the piece list is edited in source; do the same edit
+        # on the instance, then rebuild the sampler and reset, re-seeding so the
+        # stream is a function of (seed, n_pieces) only.
+        np.random.seed(seed)
+        env.tetrominos = [getattr(tetromino, n)("bcts", 8, C) for n in piece_names]
+        env.tetromino_sampler = tetromino.TetrominoSampler(env.tetrominos)
+        env.reset()
+    return env
+
+
+def gen_trajectory(game, tetromino, C, R, piece_names, seed, n_steps, with_after):
+    env = make_env(game, tetromino, C, R, piece_names, seed)
+    arng = np.random.default_rng(10_000 + seed)  # action stream, independent of np.random
+    A = 40
+    rec = {k: [] for k in ("piece", "n_valid", "n_all", "action", "cols", "obs", "reward", "done", "lines",
+                           "reset_after", "after_valid", "after_all")}
+    first_piece = env.tetrominos.index(env.current_tetromino)
+    for t in range(n_steps):
+        rec["piece"].append(env.tetrominos.index(env.current_tetromino))
+        fv, fa = env.get_after_states(include_terminal=True)
+        n_valid, n_all = fv.shape[0], fa.shape[0]
+        assert n_valid > 0
+        if with_after:
+            pv = np.zeros((A, 8), np.float64)
+            pv[:n_valid] = fv
+            pa = np.zeros((A, 8), np.float64)
+            pa[:n_all] = fa
+            rec["after_valid"].append(pv)
+            rec["after_all"].append(pa)
+        a = int(arng.integers(n_valid))
+        obs, reward, done, lines = env.step(a)
+        assert obs.dtype == np.float32
+        rec["n_valid"].append(n_valid)
+        rec["n_all"].append(n_all)
+        rec["action"].append(a)
+        rec["cols"].append(cols_of(env.current_state.representation))
+        rec["obs"].append(obs.copy())
+        rec["reward"].append(int(reward))
+        rec["done"].append(int(done))
+        rec["lines"].append(int(lines))
+        rec["reset_after"].append(int(done))
+        if done:
+            # post-done protocol: zero valid placements
+            assert env.get_after_states()[0].shape == (0, 8)
+            env.reset()
+    # piece the env holds after the last step (so the whole stream is pinned)
+    last_piece = env.tetrominos.index(env.current_tetromino)
+    out = dict(
+        first_piece=first_piece, last_piece=last_piece,
+        piece=np.array(rec["piece"], np.int8), n_valid=np.array(rec["n_valid"], np.int8),
+        n_all=np.array(rec["n_all"], np.int8), action=np.array(rec["action"], np.int16),
+        cols=np.array(rec["cols"], np.uint64), obs=np.array(rec["obs"], np.float32),
+        reward=np.array(rec["reward"], np.int32), done=np.array(rec["done"], np.int8),
+        lines=np.array(rec["lines"], np.int8))
+    if with_after:
+        out["after_valid"] = np.array(rec["after_valid"], np.float32)
+        out["after_all"] = np.array(rec["after_all"], np.float32)
+    return out
+
+
+def gen_rng():
+    out = {}
+    for n in (2, 7, 9):
+        bags = np.zeros((16, 64, n), np.int8)
+        for s in range(16):
+            np.random.seed(s)
+            for b in range(64):
+                bags[s, b] = np.random.permutation(n)
+        out[f"bags_n{n}"] = bags
+    # raw stream check: first 8 uint32 words for seeds 0..3 via randint full range
+    return out
+
+
+def gen_edges(game, state, tetromino):
+    C, R = 10, 20
+    rows = R + 4
+    out = {}
+
+    def run(name, rep, piece_name):
+        st = state.State(representation=rep.copy(), lowest_free_rows=None)
+        piece = getattr(tetromino, piece_name)("bcts", 8, C)
+        kids = piece.get_after_states(st)
+        out[name + "_board"] = cols_of(st.representation)
+        out[name + "_piece"] = np.int8(CATALOGUE.index(piece_name))
+        out[name + "_cols"] = np.array([cols_of(k.representation) for k in kids], np.uint64)
+        out[name + "_n_cleared"] = np.array([k.n_cleared_lines for k in kids], np.int8)
+        out[name + "_terminal"] = np.array([int(k.terminal_state) for k in kids], np.int8)
+        out[name + "_feats"] = np.array([k.get_features() for k in kids], np.float32)
+        return kids
+
+    # E1: three-line clear rescuing an over-height piece:
+    # cols 1..9 full to row 19, col 0 empty up to row 17; vertical ThreeLine in col 0
+    rep = np.zeros((rows, C), dtype=np.int_)
+    rep[:R, 1:] = 1
+    rep[:R - 3, 0] = 1
+    rep[0, 5] = 0  # keep row 0.. not full: a hole low down in column 5
+    rep[:R - 3, 0] = 1
+    for r in range(R - 3):
+        rep[r, 3] = 0 if r % 2 == 0 else 1  # make lower rows non-full
+    kids = run("e1_rescue", rep, "ThreeLine")
+    assert kids[0].n_cleared_lines == 3 and not kids[0].terminal_state
+
+    # E2: four-line Straight clear
+    rep = np.zeros((rows, C), dtype=np.int_)
+    rep[:4, 1:] = 1
+    kids = run("e2_tetris", rep, "Straight")
+    assert kids[0].n_cleared_lines == 4
+
+    # E3: board where exactly one placement of ThreeLine is non-terminal
+    rep = np.zeros((rows, C), dtype=np.int_)
+    rep[:R, :] = 1
+    rep[:R, 2] = 0
+    rep[0:R:2, 7] = 0  # avoid full rows after the drop... col 7 has holes
+    rep[R - 1, 7] = 1
+    kids = run("e3_onevalid", rep, "ThreeLine")
+    # E4: all placements terminal
+    rep = np.zeros((rows, C), dtype=np.int_)
+    rep[:R, :] = 1
+    rep[0:R:2, 4] = 0
+    rep[R - 1, 4] = 1
+    kids = run("e4_dead", rep, "ThreeL")
+    assert all(k.terminal_state for k in kids)
+
+    # E5: done-step reward -101 through game.Tetris, and the post-done protocol
+    np.random.seed(3)
+    env = game.Tetris(C, R)
+    arng = np.random.default_rng(77)
+    hist = []
+    while True:
+        fv, _ = env.get_after_states()
+        a = int(arng.integers(fv.shape[0]))
+        obs, reward, done, lines = env.step(a)
+        hist.append((reward, int(done), lines))
+        if done:
+            break
+    out["e5_last_reward"] = np.int32(hist[-1][0])
+    out["e5_last_lines"] = np.int32(hist[-1][2])
+    out["e5_post_done_nvalid"] = np.int32(env.get_after_states()[0].shape[0])
+    try:
+        env.step(0)
+        out["e5_post_done_step_raises"] = np.int8(0)
+    except IndexError:
+        out["e5_post_done_step_raises"] = np.int8(1)
+
+    # E6: reset state features (state.py defaults: changed_lines=[0], bonus 0)
+    env = game.Tetris(C, R)
+    st, _ = env.reset()
+    out["e6_reset_feats_20"] = st.get_features().astype(np.float32)
+    env = game.Tetris(C, 40)
+    st, _ = env.reset()
+    out["e6_reset_feats_40"] = st.get_features().astype(np.float32)
+    return out
+
+
+def gen_dtypes(game):
+    np.random.seed(0)
+    env = game.Tetris(10, 20)
+    env.get_after_states()
+    o1 = env.step(0)[0]
+    np.random.seed(0)
+    env = game.Tetris(10, 20, feature_directions=np.array([-1, -1, -1, -1, -1, -1, 1, -1]))
+    fv, _ = env.get_after_states()
+    o2 = env.step(0)[0]
+    return dict(obs_plain_dtype=str(o1.dtype), obs_directed_dtype=str(o2.dtype), obs_plain=o1, obs_directed=o2,
+                after_dtype=str(fv.dtype), after_directed=fv)
+
+
+def gen_policy_rollouts(game, tetromino):
+    """get_best_policy (game.py:102-120) on trajectory states, for section 8f-1."""
+    out = {}
+    for tag, names, R in (("default_20", None, 20), ("standard7_20", STANDARD7, 20)):
+        env = make_env(game, tetromino, 10, R, names, 5)
+        arng = np.random.default_rng(123)
+        boards, pieces, pols, fits = [], [], [], []
+        for t in range(120):
+            boards.append(cols_of(env.current_state.representation))
+            pieces.append(env.tetrominos.index(env.current_tetromino))
+            pol = env.get_best_policy()
+            p = np.zeros(40, np.float64)
+            p[:len(pol)] = pol
+            pols.append(p)
+            kids = env.current_tetromino.get_after_states(env.current_state)
+            f = np.zeros(40, np.float64)
+            f[:len(kids)] = [env.fitness(k) for k in kids]
+            fits.append(f)
+            fv, _ = env.get_after_states()
+            _, _, done, _ = env.step(int(arng.integers(fv.shape[0])))
+            if done:
+                env.reset()
+        out[tag + "_boards"] = np.array(boards, np.uint64)
+        out[tag + "_pieces"] = np.array(pieces, np.int8)
+        out[tag + "_policy"] = np.array(pols, np.float64)
+        out[tag + "_fitness"] = np.array(fits, np.float64)
+    return out
+
+
+def main():
+    game, state, tetromino = import_reference()
+    np.savez_compressed(os.path.join(HERE, "g1_placements_10x20.npz"),
+                        **gen_placements(game, state, tetromino, 20, 10, 56, seed=1))
+    np.savez_compressed(os.path.join(HERE, "g1_placements_10x40.npz"),
+                        **gen_placements(game, state, tetromino, 40, 10, 35, seed=2))
+    np.savez_compressed(os.path.join(HERE, "g1_placements_6x10.npz"),
+                        **gen_placements(game, state, tetromino, 10, 6, 21, seed=3))
+    for tag, names in (("default", None), ("standard7", STANDARD7)):
+        for R in (20, 40):
+            trajs = {}
+            for seed in range(6):
+                tr = gen_trajectory(game, tetromino, 10, R, names, seed, 300, with_after=(seed < 2))
+                for k, v in tr.items():
+                    trajs[f"s{seed}_{k}"] = v
+            np.savez_compressed(os.path.join(HERE, f"g2_traj_{tag}_10x{R}.npz"), **trajs)
+    np.savez_compressed(os.path.join(HERE, "g3_rng.npz"), **gen_rng())
+    np.savez_compressed(os.path.join(HERE, "g4_edges.npz"), **gen_edges(game, state, tetromino))
+    np.savez_compressed(os.path.join(HERE, "g5_dtypes.npz"), **gen_dtypes(game))
+    np.savez_compressed(os.path.join(HERE, "g6_policy.npz"), **gen_policy_rollouts(game, tetromino))
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith(".npz"):
+            print(f, os.path.getsize(os.path.join(HERE, f)))
+
+
+if __name__ == "__main__":
+    main()
