@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""Headline benchmark: env-steps/s of the fused Tetris step on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over the whole batch: the random-policy
+kernel (uniform valid action per env) + the fused step kernel (decode, land,
+lock, clear, done, reward, BCTS observation, in-kernel auto-reset), every output
+tensor written.  Workload at N = 1: BASELINE config 3 -- 1,048,576 envs, 10x20
+board, default piece set; N > 1 is config 4 (weak scaling, 1,048,576 envs per
+GPU, contiguous env shards, no data-path collective; RCCL only gathers the
+done counters / done bitmask).
+
+Prints ONE JSON line (rank 0).  `roofline` prices the step kernel alone against
+HBM: algorithmic bytes per env-step (2*C*W + 47 = 127 B at 10x20,
+207 B at 10x40) x envs per launch / HIP-event kernel time.  `cpu_baseline` times
+the CPU oracle (a port, oracle/) on this host's cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (guides: 8.0 TB/s; ~6.3 TB/s achievable)
+
+
+def algorithmic_bytes_per_env_step(C, word_bytes):
+    return 2 * C * word_bytes + 47
+
+
+def cpu_baseline(C, R, pieces, seconds=12.0):
+    """The oracle (CPU restatement, OpenMP over envs) on a bounded sample."""
+    from oracle import oracle as orc
+    import numpy as np
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    B = 2048 * cores
+    env = orc.OracleVecEnv(C, R, B, pieces=pieces, auto_reset=True, seed=0, nthreads=cores)
+    rng = np.random.default_rng(0)
+
+    def one():
+        a = (rng.random(B) * env.n_valid).astype(np.int32)
+        env.step(a)
+
+    for _ in range(3):
+        one()
+    t0 = time.perf_counter()
+    n = 0
+    while time.perf_counter() - t0 < seconds:
+        one()
+        n += 1
+    dt = time.perf_counter() - t0
+    return dict(value=B * n / dt, unit="env-steps/s", cores=cores, kind="port",
+                sample="%d envs x %d steps (oracle/tetris_oracle.c, OpenMP over envs, auto-reset, random "
+                       "valid actions)" % (B, n))
+
+
+def load_traffic():
+    """HBM bytes per launch from the committed PMC profile, if any (profiles/)."""
+    p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(p):
+        try:
+            return json.load(open(p)).get("step_kernel_hbm_bytes_per_launch")
+        except Exception:
+            return None
+    return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--batch", type=int, default=1 << 20, help="envs per GPU")
+    ap.add_argument("--rows", type=int, default=20)
+    ap.add_argument("--columns", type=int, default=10)
+    ap.add_argument("--pieces", default="default")
+    ap.add_argument("--gather-every", type=int, default=64)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    torch.cuda.set_device(dev)
+
+    from tetris_amd import VecTetris
+    from tetris_amd.distributed import DoneGather
+
+    B = args.batch
+    env = VecTetris(args.columns, args.rows, B, device=dev, pieces=args.pieces, auto_reset=True, seed=0,
+                    env_offset=rank * B)
+    gather = DoneGather(B)
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    def one_step(t):
+        a = env.random_actions()
+        env.step(a)
+        if world > 1 and (t + 1) % args.gather_every == 0:
+            gather.gather_counters(env.status)
+
+    for t in range(args.warmup):
+        one_step(t)
+    barrier()
+    t0 = time.perf_counter()
+    for t in range(args.steps):
+        one_step(t)
+    if world > 1:
+        gather.gather_bits(env.done)  # the done/reset gather over RCCL
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    totals = gather.gather_counters(env.status).cpu().tolist()
+
+    # step-kernel time alone, HIP events on the launch stream (torch's current stream)
+    n_prof = 50
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_prof)]
+    for s, e in evs:
+        a = env.random_actions()
+        s.record()
+        env.step(a)
+        e.record()
+    torch.cuda.synchronize(dev)
+    k_ms = sorted(s.elapsed_time(e) for s, e in evs)
+    k_ms = sum(k_ms[5:-5]) / len(k_ms[5:-5])
+    env.check()
+
+    if rank == 0:
+        alg = algorithmic_bytes_per_env_step(args.columns, env.desc.word_bytes)
+        achieved = alg * B / (k_ms * 1e-3) / 1e9
+        out = {
+            "metric": "env-steps/sec",
+            "value": B * world * args.steps / dt,
+            "unit": "env-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32" if env.desc.word_bytes == 4 else "u64",
+            "data": "synthetic",
+            "config": {"workload": "%d envs/GPU x %d GPU, %dx%d board, pieces=%s, uniform random valid actions, "
+                                   "in-kernel auto-reset, device bag seed 0" % (B, world, args.columns, args.rows,
+                                                                                args.pieces),
+                       "envs_per_gpu": B, "board": "%dx%d" % (args.columns, args.rows), "pieces": args.pieces,
+                       "sharding": "env-index ranges, no data-path collective; RCCL gathers done counters every "
+                                   "%d steps + done bitmask at the end" % args.gather_every},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(),
+                         "kernel": "step_kernel", "kernel_ms": k_ms, "algorithmic_bytes_per_env_step": alg},
+            "episodes": totals[1], "lines_cleared": totals[2],
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.columns, args.rows, args.pieces, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

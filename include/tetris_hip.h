@@ -1,0 +1,171 @@
+/*
+ * tetris_hip.h -- C-ABI of libtetris_hip.so: the MI355X (gfx950) hot path of a
+ * vectorised placement-level Tetris environment.
+ *
+ * The reference (s0phia-/tetris) is pure Python and has NO FFI / plugin
+ * interface; the surface this library replaces is the Python one of
+ * game.Tetris (+ state.State / tetromino.*).  Each entry point cites the
+ * reference lines it stands in for.  INTEGRATION.md shows the ctypes stub a
+ * reference maintainer would add to game.py to bind them.
+ *
+ * Conventions
+ *  - every pointer is DEVICE memory owned by the caller (PyTorch-ROCm tensors
+ *    in the shipped host code); the library allocates nothing persistent,
+ *    keeps no global state and never frees caller memory;
+ *  - all work is enqueued asynchronously on `stream` (a hipStream_t passed as
+ *    void*; NULL = the default stream); no implicit synchronisation;
+ *  - every function returns 0 on success, a negative TETRIS_E_* argument error
+ *    (nothing was launched), or a positive hipError_t;
+ *  - functions are re-entrant.
+ *
+ * Data layout (all [..] are element counts; B = batch)
+ *  cols  : column bitboards, plane-major: cols[c*B + i] = column c of env i;
+ *          bit r = cell (row r, column c), row 0 = bottom, rows 0..R+3 stored
+ *          (game.py:56, state.py:27-30).  Word = uint32 if R+4 <= 31,
+ *          uint64 if R+4 <= 63 (TetrisDesc.word_bytes).
+ *  meta  : uint64[B] per-env control word:
+ *            bits  0-47 valid mask over static slots s = L*2C + 2c + o
+ *                       (ascending s = reference enumeration order; the k-th
+ *                       set bit is action k, game.py:69,83)
+ *            bits 48-51 current piece (index into the piece list, game.py:38-39)
+ *            bits 52-63 bag: list indices still to be drawn (tetromino.py:12-22)
+ */
+#ifndef TETRIS_HIP_H
+#define TETRIS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TETRIS_HIP_ABI_VERSION 1
+
+#define TETRIS_MAX_PIECES 12
+#define TETRIS_MAX_COLUMNS 12
+#define TETRIS_N_CATALOGUE 9
+
+/* catalogue ids: class order of tetromino.py:33-576 */
+enum {
+  TETRIS_STRAIGHT = 0, TETRIS_SQUARE = 1, TETRIS_SNAKE_R = 2, TETRIS_THREE_LINE = 3,
+  TETRIS_THREE_L = 4, TETRIS_SNAKE_L = 5, TETRIS_T = 6, TETRIS_R_CORNER = 7, TETRIS_L_CORNER = 8
+};
+
+enum {
+  TETRIS_OK = 0,
+  TETRIS_E_NULL = -1,        /* required pointer is NULL */
+  TETRIS_E_DESC = -2,        /* descriptor not initialised / inconsistent */
+  TETRIS_E_COLUMNS = -3,     /* num_columns not built into this library */
+  TETRIS_E_ROWS = -4,        /* num_rows outside [4, 59] */
+  TETRIS_E_PIECES = -5,      /* bad piece list */
+  TETRIS_E_BATCH = -6,       /* B <= 0 */
+  TETRIS_E_STREAM = -7       /* replay stream given without cursor / length */
+};
+
+/* Constructor arguments of game.Tetris (game.py:21-23) that shape the kernels. */
+typedef struct TetrisDesc {
+  int32_t abi_version;       /* TETRIS_HIP_ABI_VERSION (set by tetris_hip_desc_init) */
+  int32_t num_columns;       /* C */
+  int32_t num_rows;          /* R = Tetris.num_rows (legal rows); stored rows = R+4 */
+  int32_t word_bytes;        /* 4 or 8, derived from R */
+  int32_t n_pieces;          /* len(Tetris.tetrominos) */
+  int32_t piece_ids[TETRIS_MAX_PIECES]; /* catalogue id per list entry */
+  int32_t a_max;             /* max raw placements of any piece in the set */
+  int32_t has_direct_by;     /* feature_directions given (game.py:26, state.py:49-50) */
+  float direct_by[8];
+} TetrisDesc;
+
+/* counters the kernels add to (uint32[4], caller zeroes them) */
+enum { TETRIS_STATUS_INVALID = 0, TETRIS_STATUS_EPISODES = 1, TETRIS_STATUS_LINES = 2, TETRIS_STATUS_STEPS = 3 };
+
+int tetris_hip_version(void);
+const char* tetris_hip_error_string(int code);
+
+/* number of columns values compiled into the library; fills out[] (<= 16) */
+int tetris_hip_supported_columns(int32_t* out, int cap);
+
+/* game.py:21-51 constructor arguments -> descriptor.  direct_by may be NULL. */
+int tetris_hip_desc_init(TetrisDesc* desc, int32_t num_columns, int32_t num_rows,
+                         const int32_t* piece_ids, int32_t n_pieces, const float* direct_by);
+
+/* raw placement count of one catalogue piece (tetromino.py loops) */
+int tetris_hip_n_placements(int32_t catalogue_id, int32_t num_columns);
+
+/*
+ * Tetris.reset (game.py:53-63): empty board, draw the first piece.
+ *  reset_mask : uint8[B] or NULL (NULL = every env)
+ *  piece_out / n_valid_out : uint8[B] or NULL, written for the envs that reset
+ *  stream/cursor/stream_len : replay mode (piece list indices, [stream_len][B]
+ *      plane-major, cursor int32[B] = next unread row); NULL = device bag
+ *  init_bag : also empty the bag (sampler construction, tetromino.py:13-15);
+ *      0 keeps it, as the reference does across resets (game.py:50 vs 53-63)
+ */
+int tetris_hip_reset(const TetrisDesc* desc, void* cols, uint64_t* meta, const uint8_t* reset_mask,
+                     uint8_t* piece_out, uint8_t* n_valid_out, const uint8_t* stream,
+                     int32_t* cursor, int64_t stream_len, int32_t init_bag, uint64_t seed,
+                     uint64_t step_idx, int64_t env_offset, int64_t B, void* hip_stream);
+
+/*
+ * Tetris.step (game.py:82-92) for every env in lockstep, fused with the
+ * placement enumeration it depends on (game.py:67-69, tetromino.py
+ * get_after_states), the line clear (state.py:121-143), is_game_over for the
+ * next piece (game.py:94-100), the BCTS observation (state.py:97-107,175-280)
+ * and, when auto_reset != 0, reset() of finished envs (game.py:53-63).
+ *
+ *  action       : int32[B] index into the non-terminal placements
+ *  obs          : float32[B][8]   observation of the chosen afterstate
+ *  reward       : int32[B]        lines - 1 (- 100 when done)   game.py:86-90
+ *  done         : uint8[B]
+ *  lines        : uint8[B]
+ *  n_valid_next : uint8[B]        non-terminal placements of the new piece
+ *                                 (after auto-reset: of the fresh episode)
+ *  piece_next   : uint8[B] or NULL  list index of the new current piece
+ *  status       : uint32[4] or NULL counters (TETRIS_STATUS_*), atomically added
+ * An out-of-range action (game.py:83 raises IndexError) leaves that env
+ * untouched, writes obs = 0, reward = 0, lines = 0 and counts it in
+ * status[TETRIS_STATUS_INVALID].
+ */
+int tetris_hip_step(const TetrisDesc* desc, void* cols, uint64_t* meta, const int32_t* action,
+                    const uint8_t* stream, int32_t* cursor, int64_t stream_len, float* obs,
+                    int32_t* reward, uint8_t* done, uint8_t* lines, uint8_t* n_valid_next,
+                    uint8_t* piece_next, uint32_t* status, int32_t auto_reset, uint64_t seed,
+                    uint64_t step_idx, int64_t env_offset, int64_t B, void* hip_stream);
+
+/*
+ * Tetris.get_after_states (game.py:67-80): BCTS features of every placement
+ * of the current piece.
+ *  feats     : float32[B][a_max][8], row k = k-th NON-terminal placement
+ *              (rows >= n_valid are zero)
+ *  n_valid   : uint8[B]
+ *  feats_all : float32[B][a_max][8] or NULL: every placement in raw order
+ *              (include_terminal=True, game.py:74-78)
+ *  n_all     : uint8[B] or NULL
+ */
+int tetris_hip_afterstates(const TetrisDesc* desc, const void* cols, const uint64_t* meta,
+                           float* feats, uint8_t* n_valid, float* feats_all, uint8_t* n_all,
+                           int64_t B, void* hip_stream);
+
+/* uniform random valid action per env: floor(u * n_valid), u from the
+ * counter-based hash (the probe policy of SURVEY section 6 / example_play) */
+int tetris_hip_policy_random(const uint8_t* n_valid, int32_t* action, uint64_t seed,
+                             uint64_t step_idx, int64_t env_offset, int64_t B, void* hip_stream);
+
+/* bitboards -> reference layout: cells int8[B][R+4][C] (State.representation,
+ * state.py:14) and heights int32[B][C] (lowest_free_rows, state.py:21-24);
+ * either output may be NULL. */
+int tetris_hip_decode(const TetrisDesc* desc, const void* cols, int8_t* cells, int32_t* heights,
+                      int64_t B, void* hip_stream);
+
+/* reference layout -> bitboards (inverse of tetris_hip_decode) */
+int tetris_hip_encode(const TetrisDesc* desc, const int8_t* cells, void* cols, int64_t B,
+                      void* hip_stream);
+
+/* recompute meta's valid mask for the piece stored in meta (used after the
+ * caller edits cols / meta directly, e.g. to restore a snapshot or set a board) */
+int tetris_hip_refresh(const TetrisDesc* desc, const void* cols, uint64_t* meta,
+                       uint8_t* n_valid_out, int64_t B, void* hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

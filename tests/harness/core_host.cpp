@@ -1,0 +1,284 @@
+// core_host.cpp -- TEST HARNESS ONLY: compiles the per-lane device logic of
+// tetris_amd/csrc/tetris_core.hpp for the host (g++) so that the CPU test
+// suite (and -fsanitize builds) can check it against the oracle without a GPU.
+// It is not part of the product: nothing under tetris_amd/ loads it, and the
+// product path (libtetris_hip.so) has no CPU fallback.
+//
+// Each function mirrors the per-env wrapper of the kernel of the same name in
+// tetris_kernels.hip, looping over envs instead of lanes.
+#include <stdint.h>
+#include <string.h>
+
+#include <type_traits>
+
+#include "../../include/tetris_hip.h"
+#include "../../tetris_amd/csrc/tetris_core.hpp"
+#include "../../tetris_amd/csrc/tetris_table.hpp"
+
+namespace {
+
+template <typename W, int C>
+void step_impl(const TetrisDesc* desc, void* cols_, uint64_t* meta, const int32_t* action, const uint8_t* stream,
+               int32_t* cursor, int64_t stream_len, float* obs, int32_t* reward, uint8_t* done, uint8_t* lines,
+               uint8_t* n_valid, uint8_t* piece_next, uint32_t* status, int auto_reset, uint64_t seed,
+               uint64_t step_idx, int64_t env_offset, int64_t B) {
+  tet::SetTable tab;
+  tet::build_table(desc, &tab);
+  tet::StepCfg cfg;
+  cfg.R = desc->num_rows;
+  cfg.n_pieces = desc->n_pieces;
+  cfg.auto_reset = auto_reset;
+  cfg.key_step = tet::hash_key(seed, step_idx * 4u + 0u);
+  cfg.key_reset = tet::hash_key(seed, step_idx * 4u + 1u);
+  cfg.has_direct_by = desc->has_direct_by;
+  for (int i = 0; i < 8; ++i) cfg.direct_by[i] = desc->direct_by[i];
+  W* cols = static_cast<W*>(cols_);
+  for (int64_t i = 0; i < B; ++i) {
+    W col[C];
+    for (int c = 0; c < C; ++c) col[c] = cols[(int64_t)c * B + i];
+    uint64_t m = meta[i];
+    int draw = -1, draw_reset = -1, cur = 0;
+    if (stream) {
+      cur = cursor[i];
+      int64_t r0 = cur < stream_len ? cur : stream_len - 1;
+      int64_t r1 = cur + 1 < stream_len ? cur + 1 : stream_len - 1;
+      draw = stream[r0 * B + i];
+      draw_reset = stream[r1 * B + i];
+    }
+    tet::StepOut out;
+    tet::env_step<W, C>(col, m, action[i], tab, cfg, (uint64_t)(env_offset + i), draw, draw_reset, out);
+    if (!out.invalid) {
+      for (int c = 0; c < C; ++c) cols[(int64_t)c * B + i] = col[c];
+      meta[i] = m;
+      if (stream) cursor[i] = cur + 1 + ((out.done && auto_reset) ? 1 : 0);
+    }
+    for (int k = 0; k < 8; ++k) obs[i * 8 + k] = out.obs[k];
+    reward[i] = out.reward;
+    done[i] = (uint8_t)out.done;
+    lines[i] = (uint8_t)out.lines;
+    n_valid[i] = (uint8_t)out.n_valid;
+    if (piece_next) piece_next[i] = (uint8_t)out.piece;
+    if (status) {
+      status[TETRIS_STATUS_INVALID] += out.invalid;
+      if (!out.invalid) {
+        status[TETRIS_STATUS_EPISODES] += out.done;
+        status[TETRIS_STATUS_LINES] += out.lines;
+        status[TETRIS_STATUS_STEPS] += 1;
+      }
+    }
+  }
+}
+
+template <typename W, int C>
+void reset_impl(const TetrisDesc* desc, void* cols_, uint64_t* meta, const uint8_t* reset_mask, uint8_t* piece_out,
+                uint8_t* n_valid_out, const uint8_t* stream, int32_t* cursor, int64_t stream_len, int init_bag,
+                uint64_t seed, uint64_t step_idx, int64_t env_offset, int64_t B) {
+  tet::SetTable tab;
+  tet::build_table(desc, &tab);
+  const uint32_t key = tet::hash_key(seed, step_idx * 4u + 2u);
+  W* cols = static_cast<W*>(cols_);
+  for (int64_t i = 0; i < B; ++i) {
+    if (reset_mask && !reset_mask[i]) continue;
+    for (int c = 0; c < C; ++c) cols[(int64_t)c * B + i] = 0;
+    uint32_t bag = init_bag ? 0u : tet::meta_bag(meta[i]);
+    int piece;
+    if (stream) {
+      int cur = cursor[i];
+      int64_t r0 = cur < stream_len ? cur : stream_len - 1;
+      piece = stream[r0 * B + i];
+      cursor[i] = cur + 1;
+    } else {
+      piece = tet::bag_draw(bag, desc->n_pieces, key, (uint64_t)(env_offset + i));
+    }
+    const uint64_t mask = tab.fullmask[piece];
+    meta[i] = tet::meta_pack(mask, piece, bag);
+    if (piece_out) piece_out[i] = (uint8_t)piece;
+    if (n_valid_out) n_valid_out[i] = (uint8_t)tet::popc(mask);
+  }
+}
+
+template <typename W, int C>
+void refresh_impl(const TetrisDesc* desc, const void* cols_, uint64_t* meta, uint8_t* n_valid_out, int64_t B) {
+  tet::SetTable tab;
+  tet::build_table(desc, &tab);
+  const W* cols = static_cast<const W*>(cols_);
+  for (int64_t i = 0; i < B; ++i) {
+    W col[C];
+    int h[C];
+    for (int c = 0; c < C; ++c) col[c] = cols[(int64_t)c * B + i];
+    tet::heights_of<W, C>(col, h);
+    const int piece = tet::meta_piece(meta[i]);
+    uint32_t d4[4];
+    for (int k = 0; k < 4; ++k) d4[k] = tab.orient[piece][k];
+    const uint64_t mask = tet::valid_mask<W, C>(col, h, d4, tab.fullmask[piece], desc->num_rows);
+    meta[i] = tet::meta_pack(mask, piece, tet::meta_bag(meta[i]));
+    if (n_valid_out) n_valid_out[i] = (uint8_t)tet::popc(mask);
+  }
+}
+
+template <typename W, int C>
+void after_impl(const TetrisDesc* desc, const void* cols_, const uint64_t* meta, float* feats, uint8_t* n_valid,
+                float* feats_all, uint8_t* n_all, int64_t B) {
+  tet::SetTable tab;
+  tet::build_table(desc, &tab);
+  const W* cols = static_cast<const W*>(cols_);
+  const int R = desc->num_rows, a_max = desc->a_max;
+  for (int64_t i = 0; i < B; ++i) {
+    W col[C];
+    int h[C];
+    for (int c = 0; c < C; ++c) col[c] = cols[(int64_t)c * B + i];
+    tet::heights_of<W, C>(col, h);
+    const int piece = tet::meta_piece(meta[i]);
+    const uint64_t full = tab.fullmask[piece];
+    const uint64_t valid = tet::meta_mask(meta[i]) & full;
+    float* out_valid = feats + i * (int64_t)a_max * 8;
+    float* out_all = feats_all ? feats_all + i * (int64_t)a_max * 8 : nullptr;
+    memset(out_valid, 0, sizeof(float) * a_max * 8);
+    if (out_all) memset(out_all, 0, sizeof(float) * a_max * 8);
+    const int nv = tet::popc(valid), na = tet::popc(full);
+    for (int lo = 0; lo < 4; ++lo) {
+      const tet::Orient o = tet::unpack_orient(tab.orient[piece][lo]);
+      if (!o.exists) continue;
+      for (int c = 0; c < C; ++c) {
+        const int s = (lo >> 1) * 2 * C + 2 * c + (lo & 1);
+        if (!((full >> s) & 1)) continue;
+        const uint64_t below = (1ull << s) - 1;
+        W nb[C];
+        W pbits[4];
+        int nh[C];
+        const int a = tet::stamp_static<W, C>(col, h, c, o, nb, pbits);
+        int eroded = 0;
+        const int k = tet::clear_lines<W, C>(nb, pbits, &eroded);
+        tet::heights_of<W, C>(nb, nh);
+        float f[8];
+        tet::bcts_features<W, C>(nb, nh, R, a, o.H, eroded, k, f);
+        if (desc->has_direct_by)
+          for (int q = 0; q < 8; ++q) f[q] *= desc->direct_by[q];
+        // cross-check of the cached mask against the direct terminal test (state.py:36 after :33)
+        const bool terminal = (a + o.H - k) > R;
+        if (terminal == (bool)((valid >> s) & 1)) {  // fail loudly in the tests
+          n_valid[i] = 255;
+          return;
+        }
+        if (out_all) memcpy(out_all + tet::popc(full & below) * 8, f, sizeof(f));
+        if ((valid >> s) & 1) memcpy(out_valid + tet::popc(valid & below) * 8, f, sizeof(f));
+      }
+    }
+    n_valid[i] = (uint8_t)nv;
+    if (n_all) n_all[i] = (uint8_t)na;
+  }
+}
+
+template <typename F>
+int dispatch(const TetrisDesc* desc, F&& f) {
+  int rc = tet::check_desc(desc);
+  if (rc) return rc;
+  switch (desc->num_columns) {
+#define TET_X(CC)                                                      \
+  case CC:                                                             \
+    if (desc->word_bytes == 4) f(uint32_t{}, std::integral_constant<int, CC>{}); \
+    else f(uint64_t{}, std::integral_constant<int, CC>{});             \
+    return 0;
+    TET_COLUMNS(TET_X)
+#undef TET_X
+    default:
+      return TETRIS_E_COLUMNS;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int tetris_host_desc_init(TetrisDesc* desc, int32_t num_columns, int32_t num_rows, const int32_t* piece_ids,
+                          int32_t n_pieces, const float* direct_by) {
+  return tet::desc_init(desc, num_columns, num_rows, piece_ids, n_pieces, direct_by);
+}
+
+int tetris_host_step(const TetrisDesc* desc, void* cols, uint64_t* meta, const int32_t* action,
+                     const uint8_t* stream, int32_t* cursor, int64_t stream_len, float* obs, int32_t* reward,
+                     uint8_t* done, uint8_t* lines, uint8_t* n_valid_next, uint8_t* piece_next, uint32_t* status,
+                     int32_t auto_reset, uint64_t seed, uint64_t step_idx, int64_t env_offset, int64_t B,
+                     void* unused) {
+  (void)unused;
+  return dispatch(desc, [&](auto w, auto c) {
+    step_impl<decltype(w), decltype(c)::value>(desc, cols, meta, action, stream, cursor, stream_len, obs, reward, done,
+                                               lines, n_valid_next, piece_next, status, auto_reset, seed, step_idx,
+                                               env_offset, B);
+  });
+}
+
+int tetris_host_reset(const TetrisDesc* desc, void* cols, uint64_t* meta, const uint8_t* reset_mask,
+                      uint8_t* piece_out, uint8_t* n_valid_out, const uint8_t* stream, int32_t* cursor,
+                      int64_t stream_len, int32_t init_bag, uint64_t seed, uint64_t step_idx, int64_t env_offset,
+                      int64_t B, void* unused) {
+  (void)unused;
+  return dispatch(desc, [&](auto w, auto c) {
+    reset_impl<decltype(w), decltype(c)::value>(desc, cols, meta, reset_mask, piece_out, n_valid_out, stream, cursor,
+                                                stream_len, init_bag, seed, step_idx, env_offset, B);
+  });
+}
+
+int tetris_host_refresh(const TetrisDesc* desc, const void* cols, uint64_t* meta, uint8_t* n_valid_out, int64_t B,
+                        void* unused) {
+  (void)unused;
+  return dispatch(desc, [&](auto w, auto c) {
+    refresh_impl<decltype(w), decltype(c)::value>(desc, cols, meta, n_valid_out, B);
+  });
+}
+
+int tetris_host_afterstates(const TetrisDesc* desc, const void* cols, const uint64_t* meta, float* feats,
+                            uint8_t* n_valid, float* feats_all, uint8_t* n_all, int64_t B, void* unused) {
+  (void)unused;
+  return dispatch(desc, [&](auto w, auto c) {
+    after_impl<decltype(w), decltype(c)::value>(desc, cols, meta, feats, n_valid, feats_all, n_all, B);
+  });
+}
+
+int tetris_host_policy_random(const uint8_t* n_valid, int32_t* action, uint64_t seed, uint64_t step_idx,
+                              int64_t env_offset, int64_t B, void* unused) {
+  (void)unused;
+  const uint32_t key = tet::hash_key(seed, step_idx * 4u + 3u);
+  for (int64_t i = 0; i < B; ++i) {
+    const uint32_t r = tet::hash_env(key, (uint64_t)(env_offset + i));
+    action[i] = (int32_t)(((uint64_t)r * (uint64_t)n_valid[i]) >> 32);
+  }
+  return 0;
+}
+
+int tetris_host_version(void) { return TETRIS_HIP_ABI_VERSION; }
+
+int tetris_host_n_placements(int32_t catalogue_id, int32_t num_columns) {
+  if (catalogue_id < 0 || catalogue_id >= TETRIS_N_CATALOGUE) return TETRIS_E_PIECES;
+  return tet::n_placements(catalogue_id, num_columns);
+}
+
+int tetris_host_decode(const TetrisDesc* desc, const void* cols, int8_t* cells, int32_t* heights, int64_t B,
+                       void* unused) {
+  (void)unused;
+  const int C = desc->num_columns, rows = desc->num_rows + 4;
+  for (int64_t i = 0; i < B; ++i)
+    for (int c = 0; c < C; ++c) {
+      uint64_t x = desc->word_bytes == 4 ? static_cast<const uint32_t*>(cols)[(int64_t)c * B + i]
+                                         : static_cast<const uint64_t*>(cols)[(int64_t)c * B + i];
+      if (heights) heights[i * C + c] = tet::bitlen(x);
+      if (cells)
+        for (int r = 0; r < rows; ++r) cells[(i * rows + r) * C + c] = (int8_t)((x >> r) & 1);
+    }
+  return 0;
+}
+
+int tetris_host_encode(const TetrisDesc* desc, const int8_t* cells, void* cols, int64_t B, void* unused) {
+  (void)unused;
+  const int C = desc->num_columns, rows = desc->num_rows + 4;
+  for (int64_t i = 0; i < B; ++i)
+    for (int c = 0; c < C; ++c) {
+      uint64_t x = 0;
+      for (int r = 0; r < rows; ++r) x |= (uint64_t)(cells[(i * rows + r) * C + c] != 0) << r;
+      if (desc->word_bytes == 4) static_cast<uint32_t*>(cols)[(int64_t)c * B + i] = (uint32_t)x;
+      else static_cast<uint64_t*>(cols)[(int64_t)c * B + i] = x;
+    }
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,192 @@
+"""Shared parity cases.  Each takes the torch device to run tetris_amd on:
+"cuda" for the parity tests proper (tests/test_gpu_parity.py, HIP kernels through
+the C-ABI) or "cpu" with the harness backend (tests/test_host_logic.py, the same
+lane logic compiled by g++ -- covers the host code and catches logic errors
+before a GPU run)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+STANDARD7 = ["Straight", "RCorner", "LCorner", "Square", "SnakeR", "SnakeL", "T"]
+
+
+def lockstep(device, orc, C, R, B, pieces, steps, seed, auto_reset=True, env_offset=0, check_after_every=0):
+    from tetris_amd import VecTetris
+    env = VecTetris(C, R, B, device=device, pieces=pieces, auto_reset=auto_reset, seed=seed, env_offset=env_offset)
+    ref = orc.OracleVecEnv(C, R, B, pieces=pieces, auto_reset=auto_reset, seed=seed, env_offset=env_offset,
+                           nthreads=0)
+    np.testing.assert_array_equal(env.piece.cpu().numpy(), ref.piece)
+    np.testing.assert_array_equal(env.n_valid.cpu().numpy(), ref.n_valid)
+    episodes = 0
+    for t in range(steps):
+        if check_after_every and t % check_after_every == 0:
+            f, nv, fa, na = env.get_after_states(include_terminal=True)
+            rf, rnv, rfa, rna = ref.afterstates(include_terminal=True)
+            np.testing.assert_array_equal(nv.cpu().numpy(), rnv)
+            np.testing.assert_array_equal(na.cpu().numpy(), rna)
+            np.testing.assert_array_equal(f.cpu().numpy(), rf)
+            np.testing.assert_array_equal(fa.cpu().numpy(), rfa)
+        a = env.random_actions().clone()
+        obs, rew, done, lines = env.step(a)
+        o_obs, o_rew, o_done, o_lines, n_bad = ref.step(a.cpu().numpy())
+        assert n_bad == 0
+        np.testing.assert_array_equal(obs.cpu().numpy(), o_obs, err_msg="obs t=%d" % t)  # bit-exact float32
+        np.testing.assert_array_equal(rew.cpu().numpy(), o_rew)
+        np.testing.assert_array_equal(done.cpu().numpy(), o_done.astype(bool))
+        np.testing.assert_array_equal(lines.cpu().numpy(), o_lines)
+        np.testing.assert_array_equal(env.n_valid.cpu().numpy(), ref.n_valid)
+        np.testing.assert_array_equal(env.piece.cpu().numpy(), ref.piece)
+        np.testing.assert_array_equal(env.boards().cpu().numpy(), ref.cells)
+        episodes += int(o_done.sum())
+    st = env.stats()
+    assert st["invalid"] == 0 and st["episodes"] == episodes and st["steps"] == steps * B
+    return episodes
+
+
+def lockstep_small(device, orc, C, R, pieces, B=1024 + 37, steps=150):
+    episodes = lockstep(device, orc, C, R, B, pieces, steps=steps, seed=11, check_after_every=25)
+    assert episodes > 0
+
+
+def cfg2_bit_exact(device, orc, B=65536, steps=96):
+    """BASELINE config 2: 65,536 envs, 10x20, random actions, every output every step."""
+    episodes = lockstep(device, orc, 10, 20, B, "default", steps=steps, seed=0)
+    assert episodes > B // 64
+
+
+def no_auto_reset_and_invalid_actions(device, orc, B=4096):
+    from tetris_amd import VecTetris
+    env = VecTetris(10, 20, B, device=device, seed=5)
+    ref = orc.OracleVecEnv(10, 20, B, seed=5)
+    for t in range(80):
+        a = env.random_actions().clone()
+        # finished envs have n_valid == 0: any action is out of range there
+        obs, rew, done, lines = env.step(a)
+        ref.step(a.cpu().numpy())
+        live = ref.invalid == 0
+        np.testing.assert_array_equal(env.boards().cpu().numpy(), ref.cells)
+        np.testing.assert_array_equal(obs.cpu().numpy()[live], ref.obs[live])
+        np.testing.assert_array_equal(rew.cpu().numpy()[live], ref.reward[live])
+        np.testing.assert_array_equal(env.n_valid.cpu().numpy(), ref.n_valid)
+    assert env.stats()["invalid"] > 0
+    with pytest.raises(IndexError):
+        env.check()
+    # host-driven reset of the finished envs only; the bag survives (game.py:50)
+    dead = env.n_valid == 0
+    assert dead.any()
+    env.reset(mask=dead)
+    cells = env.boards()
+    assert not cells[dead].any() and (env.n_valid[dead] > 0).all()
+
+
+def golden_trajectories_replay(device, orc, golden_dir):
+    """Recorded game.Tetris runs (live reference, NumPy MT19937 piece stream) replayed
+    through the HIP kernels: all seeds of one config form one batch."""
+    from tetris_amd import VecTetris
+    for tag, R in (("default", 20), ("default", 40), ("standard7", 20), ("standard7", 40)):
+        g = np.load(os.path.join(golden_dir, "g2_traj_%s_10x%d.npz" % (tag, R)))
+        seeds = range(6)
+        T = len(g["s0_action"])
+        pieces = "default" if tag == "default" else STANDARD7
+        n_pieces = len(pieces) if tag != "default" else 2
+        streams = []
+        for s in seeds:
+            rng = orc.NumpyLegacyRNG(s)
+            bag = orc.BagSampler(rng, n_pieces)
+            n_draws = 1 + T + int(g["s%d_done" % s].sum())
+            streams.append([bag.next() for _ in range(n_draws)] + [0] * (2 * T))
+        L = min(len(x) for x in streams)
+        stream = np.array([x[:L] for x in streams], np.uint8).T.copy()  # [L, B]
+        env = VecTetris(10, R, len(seeds), device=device, pieces=pieces, auto_reset=True, piece_stream=stream)
+        for t in range(T):
+            act = np.array([g["s%d_action" % s][t] for s in seeds], np.int32)
+            np.testing.assert_array_equal(env.piece.cpu().numpy(), [g["s%d_piece" % s][t] for s in seeds])
+            np.testing.assert_array_equal(env.n_valid.cpu().numpy(), [g["s%d_n_valid" % s][t] for s in seeds])
+            if t < 40:
+                f, nv, fa, na = env.get_after_states(include_terminal=True)
+                for i, s in enumerate(seeds):
+                    if ("s%d_after_valid" % s) in g:
+                        np.testing.assert_array_equal(f[i].cpu().numpy(), g["s%d_after_valid" % s][t][:env.a_max])
+                        np.testing.assert_array_equal(fa[i].cpu().numpy(), g["s%d_after_all" % s][t][:env.a_max])
+            obs, rew, done, lines = env.step(torch.from_numpy(act))
+            cols = env.cols.cpu().numpy().astype(np.uint64).T  # [B, C]
+            for i, s in enumerate(seeds):
+                np.testing.assert_array_equal(obs[i].cpu().numpy(), g["s%d_obs" % s][t])
+                assert int(rew[i]) == g["s%d_reward" % s][t] and bool(done[i]) == bool(g["s%d_done" % s][t])
+                assert int(lines[i]) == g["s%d_lines" % s][t]
+                if not g["s%d_done" % s][t]:
+                    np.testing.assert_array_equal(cols[i] & np.uint64((1 << (R + 4)) - 1), g["s%d_cols" % s][t])
+        assert env.stats()["invalid"] == 0
+
+
+def golden_placements_afterstates(device, orc, golden_dir):
+    """g1 fixtures: every placement of all 9 pieces on hand-made boards, via set_boards + afterstates."""
+    from tetris_amd import VecTetris
+    from tetris_amd.tetromino import CATALOGUE
+    for name in ("g1_placements_10x20.npz", "g1_placements_10x40.npz", "g1_placements_6x10.npz"):
+        g = np.load(os.path.join(golden_dir, name))
+        R, C = int(g["R"]), int(g["C"])
+        boards = g["boards"]
+        nb = len(boards)
+        cells = orc.cols_to_cells(boards, R + 4)
+        env = VecTetris(C, R, nb, device=device, pieces=list(CATALOGUE))
+        for pi in range(len(CATALOGUE)):
+            env.set_boards(cells, piece=np.full(nb, pi))
+            f, nv, fa, na = env.get_after_states(include_terminal=True)
+            fa, na, f, nv = fa.cpu().numpy(), na.cpu().numpy(), f.cpu().numpy(), nv.cpu().numpy()
+            for b in range(nb):
+                sel = (g["board_ix"] == b) & (g["piece"] == pi)
+                want = g["feats"][sel]
+                term = g["terminal"][sel].astype(bool)
+                assert na[b] == len(want) and nv[b] == int((~term).sum())
+                np.testing.assert_array_equal(fa[b, :na[b]], want)
+                np.testing.assert_array_equal(f[b, :nv[b]], want[~term])
+                assert env.n_valid[b] == nv[b]
+
+
+def sharding_equals_single_batch(device, B=2048):
+    """Two shards with env_offset draw the same pieces as one batch (multi-GPU layout, section 8e)."""
+    from tetris_amd import VecTetris
+    whole = VecTetris(10, 20, B, device=device, auto_reset=True, seed=9)
+    lo = VecTetris(10, 20, B // 2, device=device, auto_reset=True, seed=9, env_offset=0)
+    hi = VecTetris(10, 20, B // 2, device=device, auto_reset=True, seed=9, env_offset=B // 2)
+    for t in range(100):
+        a = whole.random_actions().clone()
+        whole.step(a)
+        lo.step(a[:B // 2].contiguous())
+        hi.step(a[B // 2:].contiguous())
+    assert torch.equal(whole.cols, torch.cat([lo.cols, hi.cols], dim=1))
+    assert torch.equal(whole.obs, torch.cat([lo.obs, hi.obs]))
+    assert torch.equal(whole.meta, torch.cat([lo.meta, hi.meta]))
+
+
+def full_size_properties(device, B=1 << 20, steps=60, R=20):
+    """BASELINE config 3 size (1,048,576 envs): size-independent invariants."""
+    from tetris_amd import VecTetris
+    env = VecTetris(10, R, B, device=device, auto_reset=True, seed=1)
+    cells_before = None
+    total_lines = 0
+    for t in range(steps):
+        a = env.random_actions()
+        before = env.boards().sum(dim=(1, 2), dtype=torch.int32) if t % 20 == 0 else None
+        piece_cells = 3  # both default pieces have 3 cells
+        obs, rew, done, lines = env.step(a)
+        if before is not None:
+            after = env.boards().sum(dim=(1, 2), dtype=torch.int32)
+            keep = ~done
+            # cell conservation: +piece cells, -10 per cleared line
+            assert torch.equal(after[keep], (before + piece_cells - 10 * lines.to(torch.int32))[keep])
+            assert (after[done] == 0).all()
+        assert torch.equal(rew, lines.to(torch.int32) - 1 - 100 * done.to(torch.int32))
+        h = env.heights()
+        assert int(h.max()) <= R  # playable states never reach the overflow rows
+        assert ((env.n_valid > 0) | ~done).all()
+    st = env.stats()
+    assert st["invalid"] == 0 and st["steps"] == steps * B and st["episodes"] > 0
+    # no full row survives in any board
+    full = env.cols[0]
+    for c in range(1, 10):
+        full = full & env.cols[c]
+    assert not full.any()

@@ -1,0 +1,45 @@
+"""Parity tests proper: the HIP kernels (through the C-ABI, via tetris_amd)
+against the CPU oracle and the golden fixtures.  Need a real MI355X."""
+import pytest
+
+import parity_cases as pc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.mark.parametrize("C,R,pieces", [(10, 20, "default"), (10, 20, "standard7"), (10, 40, "default"),
+                                        (10, 40, "standard7"), (6, 10, "standard7"), (8, 12, "default")])
+def test_lockstep_small(orc, C, R, pieces):
+    pc.lockstep_small(DEV, orc, C, R, pieces)
+
+
+def test_cfg2_batch_65536_bit_exact(orc):
+    """BASELINE config 2: 65,536 envs, 10x20, random actions, every output every step."""
+    pc.cfg2_bit_exact(DEV, orc)
+
+
+def test_no_auto_reset_and_invalid_actions(orc):
+    pc.no_auto_reset_and_invalid_actions(DEV, orc)
+
+
+def test_golden_trajectories_replay(orc, golden_dir):
+    pc.golden_trajectories_replay(DEV, orc, golden_dir)
+
+
+def test_golden_placements_afterstates(orc, golden_dir):
+    pc.golden_placements_afterstates(DEV, orc, golden_dir)
+
+
+def test_sharding_equals_single_batch():
+    pc.sharding_equals_single_batch(DEV)
+
+
+def test_full_size_properties():
+    """BASELINE config 3 size: 1,048,576 envs."""
+    pc.full_size_properties(DEV)
+
+
+def test_tall_board_cfg5_properties():
+    """BASELINE config 5: 10x40 (u64 columns) + auto-reset, size-independent invariants at 1M envs."""
+    pc.full_size_properties(DEV, R=40, steps=100)

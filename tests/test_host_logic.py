@@ -1,0 +1,35 @@
+"""Host logic + lane logic on CPU: tetris_amd bound to the g++ harness build of
+csrc/tetris_core.hpp (tests/harness).  Same cases as tests/test_gpu_parity.py at
+sizes that finish in seconds; no HIP code runs here."""
+import pytest
+
+import parity_cases as pc
+
+DEV = "cpu"
+
+
+@pytest.mark.parametrize("C,R,pieces", [(10, 20, "default"), (10, 20, "standard7"), (10, 40, "default"),
+                                        (6, 10, "standard7"), (8, 12, "default")])
+def test_lockstep_small(host_backend, orc, C, R, pieces):
+    pc.lockstep_small(DEV, orc, C, R, pieces, B=257, steps=120)
+
+
+def test_no_auto_reset_and_invalid_actions(host_backend, orc):
+    pc.no_auto_reset_and_invalid_actions(DEV, orc, B=512)
+
+
+def test_golden_trajectories_replay(host_backend, orc, golden_dir):
+    pc.golden_trajectories_replay(DEV, orc, golden_dir)
+
+
+def test_golden_placements_afterstates(host_backend, orc, golden_dir):
+    pc.golden_placements_afterstates(DEV, orc, golden_dir)
+
+
+def test_sharding_equals_single_batch(host_backend):
+    pc.sharding_equals_single_batch(DEV, B=512)
+
+
+def test_properties(host_backend):
+    pc.full_size_properties(DEV, B=4096, steps=60)
+    pc.full_size_properties(DEV, B=2048, R=40, steps=100)

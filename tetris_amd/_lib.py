@@ -1,0 +1,117 @@
+"""ctypes binding of libtetris_hip.so (the C-ABI declared in include/tetris_hip.h).
+
+There is no CPU fallback: if the shared library is missing this module raises,
+and every call maps a non-zero return code to an exception.
+"""
+import ctypes
+import os
+
+from . import build as _build
+
+MAX_PIECES = 12
+ABI_VERSION = 1
+
+
+class TetrisDesc(ctypes.Structure):
+    """Mirror of ``struct TetrisDesc`` (include/tetris_hip.h)."""
+    _fields_ = [
+        ("abi_version", ctypes.c_int32),
+        ("num_columns", ctypes.c_int32),
+        ("num_rows", ctypes.c_int32),
+        ("word_bytes", ctypes.c_int32),
+        ("n_pieces", ctypes.c_int32),
+        ("piece_ids", ctypes.c_int32 * MAX_PIECES),
+        ("a_max", ctypes.c_int32),
+        ("has_direct_by", ctypes.c_int32),
+        ("direct_by", ctypes.c_float * 8),
+    ]
+
+
+class TetrisHipError(RuntimeError):
+    pass
+
+
+_vp, _i32, _i64, _u64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_uint64
+_dp = ctypes.POINTER(TetrisDesc)
+
+# name -> argtypes; every function returns int (0 = ok)
+SIGNATURES = {
+    "tetris_hip_version": [],
+    "tetris_hip_supported_columns": [_vp, ctypes.c_int],
+    "tetris_hip_desc_init": [_dp, _i32, _i32, _vp, _i32, _vp],
+    "tetris_hip_n_placements": [_i32, _i32],
+    "tetris_hip_reset": [_dp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _u64, _u64, _i64, _i64, _vp],
+    "tetris_hip_step": [_dp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _u64, _u64,
+                        _i64, _i64, _vp],
+    "tetris_hip_afterstates": [_dp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
+    "tetris_hip_policy_random": [_vp, _vp, _u64, _u64, _i64, _i64, _vp],
+    "tetris_hip_decode": [_dp, _vp, _vp, _vp, _i64, _vp],
+    "tetris_hip_encode": [_dp, _vp, _vp, _i64, _vp],
+    "tetris_hip_refresh": [_dp, _vp, _vp, _vp, _i64, _vp],
+}
+EXPORTS = list(SIGNATURES) + ["tetris_hip_error_string"]
+
+
+class _Binding:
+    """Typed view of a library exporting the C-ABI (prefix selects the symbol family)."""
+
+    def __init__(self, cdll, prefix="tetris_hip_", device_type="cuda"):
+        self.cdll = cdll
+        self.device_type = device_type
+        for name, argtypes in SIGNATURES.items():
+            sym = prefix + name[len("tetris_hip_"):]
+            if not hasattr(cdll, sym):
+                continue
+            fn = getattr(cdll, sym)
+            fn.argtypes = argtypes
+            fn.restype = ctypes.c_int
+            setattr(self, name[len("tetris_hip_"):], fn)
+        if hasattr(cdll, prefix + "error_string"):
+            self._errstr = getattr(cdll, prefix + "error_string")
+            self._errstr.argtypes = [ctypes.c_int]
+            self._errstr.restype = ctypes.c_char_p
+        else:
+            self._errstr = None
+
+    def error_string(self, code):
+        if self._errstr is not None:
+            return self._errstr(code).decode()
+        return "error %d" % code
+
+    def check(self, code, what):
+        if code != 0:
+            raise TetrisHipError("%s failed: %s (code %d)" % (what, self.error_string(code), code))
+
+
+_BINDING = None
+
+
+def load():
+    """Load (building if the sources are newer and hipcc exists) libtetris_hip.so."""
+    global _BINDING
+    if _BINDING is not None:
+        return _BINDING
+    path = _build.SO_PATH
+    if _build.is_stale():
+        try:
+            _build.build_hip()
+        except Exception as exc:  # no hipcc on this machine
+            if not os.path.exists(path):
+                raise ImportError(
+                    "tetris_amd needs its HIP extension %s and it could not be built: %s. "
+                    "Run `python -m tetris_amd.build` on a machine with hipcc." % (path, exc))
+    cdll = ctypes.CDLL(path)
+    b = _Binding(cdll)
+    if b.version() != ABI_VERSION:
+        raise ImportError("libtetris_hip.so ABI %d != expected %d" % (b.version(), ABI_VERSION))
+    _BINDING = b
+    return b
+
+
+def _install_test_backend(binding):
+    """TEST-SUITE HOOK ONLY (tests/harness): swap the binding so the host logic
+    can be exercised on CPU tensors.  Never called by the package itself."""
+    global _BINDING
+    old = _BINDING
+    _BINDING = binding
+    return old

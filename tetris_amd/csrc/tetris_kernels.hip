@@ -1,0 +1,536 @@
+// tetris_kernels.hip -- gfx950 kernels + the C-ABI of include/tetris_hip.h.
+//
+// One lane per env; column bitboards in plane-major (SoA) HBM layout so that a
+// wave64 reads/writes 256 contiguous bytes (u32) or 512 (u64) per column plane.
+// No dense contraction anywhere -> no MFMA; the path is HBM-streaming integer
+// bit work (popcount / clz / shifts) with the per-set piece table staged in LDS.
+#include <hip/hip_runtime.h>
+#include <string.h>
+
+#include "../../include/tetris_hip.h"
+#include "tetris_core.hpp"
+#include "tetris_table.hpp"
+
+namespace {
+
+using tet::SetTable;
+using tet::StepCfg;
+using tet::build_table;
+using tet::n_placements;
+using tet::check_desc;
+
+constexpr int kBlock = 256;
+
+// ---- kernels ------------------------------------------------------------------
+
+__device__ __forceinline__ void stage_table(SetTable& lds, const SetTable& arg) {
+  const uint32_t* src = reinterpret_cast<const uint32_t*>(&arg);
+  uint32_t* dst = reinterpret_cast<uint32_t*>(&lds);
+  for (int t = threadIdx.x; t < (int)(sizeof(SetTable) / 4); t += blockDim.x) dst[t] = src[t];
+  __syncthreads();
+}
+
+__device__ __forceinline__ void wave_count(uint32_t* counter, int value_bits, int v) {
+  // sum of small per-lane integers through ballots; one atomic per wave, only if nonzero
+  unsigned total = 0;
+  for (int b = 0; b < value_bits; ++b) {
+    unsigned long long m = __ballot((v >> b) & 1);
+    total += (unsigned)__popcll(m) << b;
+  }
+  if (total != 0 && (threadIdx.x & 63) == 0) atomicAdd(counter, total);
+}
+
+struct StepParams {
+  void* cols;
+  uint64_t* meta;
+  const int32_t* action;
+  const uint8_t* stream;
+  int32_t* cursor;
+  int64_t stream_len;
+  float* obs;
+  int32_t* reward;
+  uint8_t* done;
+  uint8_t* lines;
+  uint8_t* n_valid;
+  uint8_t* piece_next;
+  uint32_t* status;
+  int64_t B;
+  int64_t env_offset;
+  StepCfg cfg;
+  SetTable tab;
+};
+
+template <typename W, int C>
+__global__ __launch_bounds__(kBlock) void step_kernel(const StepParams p) {
+  __shared__ SetTable tab;
+  stage_table(tab, p.tab);
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const bool live = i < p.B;
+  int invalid = 0, done = 0, lines = 0;
+  if (live) {
+    W* cols = static_cast<W*>(p.cols);
+    W col[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) col[c] = cols[(int64_t)c * p.B + i];
+    uint64_t meta = p.meta[i];
+    const int action = p.action[i];
+    int draw = -1, draw_reset = -1, cur = 0;
+    if (p.stream) {
+      cur = p.cursor[i];
+      int64_t r0 = cur < p.stream_len ? cur : p.stream_len - 1;
+      int64_t r1 = cur + 1 < p.stream_len ? cur + 1 : p.stream_len - 1;
+      draw = p.stream[r0 * p.B + i];
+      draw_reset = p.stream[r1 * p.B + i];
+    }
+    tet::StepOut out;
+    tet::env_step<W, C>(col, meta, action, tab, p.cfg, (uint64_t)(p.env_offset + i), draw, draw_reset, out);
+    invalid = out.invalid;
+    if (!invalid) {
+#pragma unroll
+      for (int c = 0; c < C; ++c) cols[(int64_t)c * p.B + i] = col[c];
+      p.meta[i] = meta;
+      done = out.done;
+      lines = out.lines;
+      if (p.stream) p.cursor[i] = cur + 1 + ((out.done && p.cfg.auto_reset) ? 1 : 0);
+    }
+    float4* o4 = reinterpret_cast<float4*>(p.obs + i * 8);
+    o4[0] = make_float4(out.obs[0], out.obs[1], out.obs[2], out.obs[3]);
+    o4[1] = make_float4(out.obs[4], out.obs[5], out.obs[6], out.obs[7]);
+    p.reward[i] = out.reward;
+    p.done[i] = (uint8_t)out.done;
+    p.lines[i] = (uint8_t)out.lines;
+    p.n_valid[i] = (uint8_t)out.n_valid;
+    if (p.piece_next) p.piece_next[i] = (uint8_t)out.piece;
+  }
+  if (p.status) {
+    wave_count(p.status + TETRIS_STATUS_INVALID, 1, invalid);
+    wave_count(p.status + TETRIS_STATUS_EPISODES, 1, done);
+    wave_count(p.status + TETRIS_STATUS_LINES, 3, lines);
+    wave_count(p.status + TETRIS_STATUS_STEPS, 1, (live && !invalid) ? 1 : 0);
+  }
+}
+
+struct ResetParams {
+  void* cols;
+  uint64_t* meta;
+  const uint8_t* reset_mask;
+  uint8_t* piece_out;
+  uint8_t* n_valid_out;
+  const uint8_t* stream;
+  int32_t* cursor;
+  int64_t stream_len;
+  int64_t B;
+  int64_t env_offset;
+  int32_t init_bag;
+  int32_t n_pieces;
+  uint32_t key;
+  SetTable tab;
+};
+
+template <typename W, int C>
+__global__ __launch_bounds__(kBlock) void reset_kernel(const ResetParams p) {
+  __shared__ SetTable tab;
+  stage_table(tab, p.tab);
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= p.B) return;
+  if (p.reset_mask && !p.reset_mask[i]) return;
+  W* cols = static_cast<W*>(p.cols);
+#pragma unroll
+  for (int c = 0; c < C; ++c) cols[(int64_t)c * p.B + i] = 0;  // game.py:55-58
+  uint32_t bag = p.init_bag ? 0u : tet::meta_bag(p.meta[i]);
+  int piece;
+  if (p.stream) {
+    int cur = p.cursor[i];
+    int64_t r0 = cur < p.stream_len ? cur : p.stream_len - 1;
+    piece = p.stream[r0 * p.B + i];
+    p.cursor[i] = cur + 1;
+  } else {
+    piece = tet::bag_draw(bag, p.n_pieces, p.key, (uint64_t)(p.env_offset + i));  // game.py:60
+  }
+  const uint64_t mask = tab.fullmask[piece];
+  p.meta[i] = tet::meta_pack(mask, piece, bag);
+  if (p.piece_out) p.piece_out[i] = (uint8_t)piece;
+  if (p.n_valid_out) p.n_valid_out[i] = (uint8_t)tet::popc(mask);
+}
+
+struct RefreshParams {
+  const void* cols;
+  uint64_t* meta;
+  uint8_t* n_valid_out;
+  int64_t B;
+  int32_t R;
+  SetTable tab;
+};
+
+template <typename W, int C>
+__global__ __launch_bounds__(kBlock) void refresh_kernel(const RefreshParams p) {
+  __shared__ SetTable tab;
+  stage_table(tab, p.tab);
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= p.B) return;
+  const W* cols = static_cast<const W*>(p.cols);
+  W col[C];
+  int h[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) col[c] = cols[(int64_t)c * p.B + i];
+  tet::heights_of<W, C>(col, h);
+  const uint64_t meta = p.meta[i];
+  const int piece = tet::meta_piece(meta);
+  uint32_t d4[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) d4[k] = tab.orient[piece][k];
+  const uint64_t mask = tet::valid_mask<W, C>(col, h, d4, tab.fullmask[piece], p.R);
+  p.meta[i] = tet::meta_pack(mask, piece, tet::meta_bag(meta));
+  if (p.n_valid_out) p.n_valid_out[i] = (uint8_t)tet::popc(mask);
+}
+
+struct AfterParams {
+  const void* cols;
+  const uint64_t* meta;
+  float* feats;
+  uint8_t* n_valid;
+  float* feats_all;
+  uint8_t* n_all;
+  int64_t B;
+  int32_t R;
+  int32_t a_max;
+  int32_t has_direct_by;
+  float direct_by[8];
+  SetTable tab;
+};
+
+// game.py:67-80.  One lane per env walks the static slots in reference order;
+// the k-th non-terminal placement lands in feats[i][k].
+template <typename W, int C>
+__global__ __launch_bounds__(kBlock) void afterstates_kernel(const AfterParams p) {
+  __shared__ SetTable tab;
+  stage_table(tab, p.tab);
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= p.B) return;
+  const W* cols = static_cast<const W*>(p.cols);
+  W col[C];
+  int h[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) col[c] = cols[(int64_t)c * p.B + i];
+  tet::heights_of<W, C>(col, h);
+  const uint64_t meta = p.meta[i];
+  const int piece = tet::meta_piece(meta);
+  const uint64_t full = tab.fullmask[piece];
+  const uint64_t valid = tet::meta_mask(meta) & full;  // non-terminal slots (kept fresh by step/reset/refresh)
+  float* out_valid = p.feats + i * (int64_t)p.a_max * 8;
+  float* out_all = p.feats_all ? p.feats_all + i * (int64_t)p.a_max * 8 : nullptr;
+  const int nv = tet::popc(valid), na = tet::popc(full);
+#pragma unroll 1
+  for (int lo = 0; lo < 4; ++lo) {
+    const tet::Orient o = tet::unpack_orient(tab.orient[piece][lo]);
+    if (!o.exists) continue;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      // slot order (loop, column, orientation) is the reference's enumeration order,
+      // so the row of a placement is the number of set bits below its slot
+      const int s = (lo >> 1) * 2 * C + 2 * c + (lo & 1);
+      if (!((full >> s) & 1)) continue;
+      const uint64_t below = (1ull << s) - 1;
+      W nb[C];
+      W pbits[4];
+      int nh[C];
+      const int a = tet::stamp_static<W, C>(col, h, c, o, nb, pbits);
+      int eroded = 0;
+      const int k = tet::clear_lines<W, C>(nb, pbits, &eroded);
+      tet::heights_of<W, C>(nb, nh);
+      float f[8];
+      tet::bcts_features<W, C>(nb, nh, p.R, a, o.H, eroded, k, f);
+      if (p.has_direct_by) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) f[q] *= p.direct_by[q];
+      }
+      if (out_all) {
+        float4* d = reinterpret_cast<float4*>(out_all + tet::popc(full & below) * 8);
+        d[0] = make_float4(f[0], f[1], f[2], f[3]);
+        d[1] = make_float4(f[4], f[5], f[6], f[7]);
+      }
+      if ((valid >> s) & 1) {  // game.py:69
+        float4* d = reinterpret_cast<float4*>(out_valid + tet::popc(valid & below) * 8);
+        d[0] = make_float4(f[0], f[1], f[2], f[3]);
+        d[1] = make_float4(f[4], f[5], f[6], f[7]);
+      }
+    }
+  }
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int k = nv; k < p.a_max; ++k) {
+    float4* d = reinterpret_cast<float4*>(out_valid + k * 8);
+    d[0] = z;
+    d[1] = z;
+  }
+  if (out_all)
+    for (int k = na; k < p.a_max; ++k) {
+      float4* d = reinterpret_cast<float4*>(out_all + k * 8);
+      d[0] = z;
+      d[1] = z;
+    }
+  p.n_valid[i] = (uint8_t)nv;
+  if (p.n_all) p.n_all[i] = (uint8_t)na;
+}
+
+__global__ __launch_bounds__(kBlock) void policy_random_kernel(const uint8_t* __restrict__ n_valid,
+                                                               int32_t* __restrict__ action, uint32_t key,
+                                                               int64_t env_offset, int64_t B) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= B) return;
+  const uint32_t r = tet::hash_env(key, (uint64_t)(env_offset + i));
+  action[i] = (int32_t)(((uint64_t)r * (uint64_t)n_valid[i]) >> 32);
+}
+
+template <typename W>
+__global__ __launch_bounds__(kBlock) void decode_kernel(const W* __restrict__ cols, int8_t* __restrict__ cells,
+                                                        int32_t* __restrict__ heights, int C, int rows, int64_t B) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= B) return;
+  for (int c = 0; c < C; ++c) {
+    const W x = cols[(int64_t)c * B + i];
+    if (heights) heights[i * C + c] = tet::bitlen(x);
+    if (cells)
+      for (int r = 0; r < rows; ++r) cells[(i * rows + r) * C + c] = (int8_t)((x >> r) & 1);
+  }
+}
+
+template <typename W>
+__global__ __launch_bounds__(kBlock) void encode_kernel(const int8_t* __restrict__ cells, W* __restrict__ cols,
+                                                        int C, int rows, int64_t B) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= B) return;
+  for (int c = 0; c < C; ++c) {
+    W x = 0;
+    for (int r = 0; r < rows; ++r) x |= (W)(cells[(i * rows + r) * C + c] != 0) << r;
+    cols[(int64_t)c * B + i] = x;
+  }
+}
+
+// ---- dispatch on (word, C) -------------------------------------------------------
+
+inline dim3 grid_for(int64_t B) { return dim3((unsigned)((B + kBlock - 1) / kBlock)); }
+
+template <template <typename, int> class Launcher, typename P>
+int dispatch(const TetrisDesc* d, const P& p, hipStream_t s) {
+  switch (d->num_columns) {
+#define X(CC)                                                       \
+  case CC:                                                          \
+    if (d->word_bytes == 4) Launcher<uint32_t, CC>::run(p, s);      \
+    else Launcher<uint64_t, CC>::run(p, s);                         \
+    break;
+    TET_COLUMNS(X)
+#undef X
+    default:
+      return TETRIS_E_COLUMNS;
+  }
+  return (int)hipGetLastError();
+}
+
+template <typename W, int C>
+struct LaunchStep {
+  static void run(const StepParams& p, hipStream_t s) {
+    hipLaunchKernelGGL((step_kernel<W, C>), grid_for(p.B), dim3(kBlock), 0, s, p);
+  }
+};
+template <typename W, int C>
+struct LaunchReset {
+  static void run(const ResetParams& p, hipStream_t s) {
+    hipLaunchKernelGGL((reset_kernel<W, C>), grid_for(p.B), dim3(kBlock), 0, s, p);
+  }
+};
+template <typename W, int C>
+struct LaunchRefresh {
+  static void run(const RefreshParams& p, hipStream_t s) {
+    hipLaunchKernelGGL((refresh_kernel<W, C>), grid_for(p.B), dim3(kBlock), 0, s, p);
+  }
+};
+template <typename W, int C>
+struct LaunchAfter {
+  static void run(const AfterParams& p, hipStream_t s) {
+    hipLaunchKernelGGL((afterstates_kernel<W, C>), grid_for(p.B), dim3(kBlock), 0, s, p);
+  }
+};
+
+}  // namespace
+
+// ---- C-ABI ---------------------------------------------------------------------------
+extern "C" {
+
+int tetris_hip_version(void) { return TETRIS_HIP_ABI_VERSION; }
+
+const char* tetris_hip_error_string(int code) {
+  switch (code) {
+    case TETRIS_OK: return "ok";
+    case TETRIS_E_NULL: return "required pointer is NULL";
+    case TETRIS_E_DESC: return "descriptor not initialised by tetris_hip_desc_init or inconsistent";
+    case TETRIS_E_COLUMNS: return "num_columns not compiled into libtetris_hip";
+    case TETRIS_E_ROWS: return "num_rows outside [4, 59]";
+    case TETRIS_E_PIECES: return "bad piece list";
+    case TETRIS_E_BATCH: return "batch size must be positive";
+    case TETRIS_E_STREAM: return "replay stream needs cursor and stream_len > 0";
+    default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown error";
+  }
+}
+
+int tetris_hip_supported_columns(int32_t* out, int cap) {
+  int n = 0;
+#define X(CC) if (out && n < cap) out[n] = CC; ++n;
+  TET_COLUMNS(X)
+#undef X
+  return n;
+}
+
+int tetris_hip_n_placements(int32_t catalogue_id, int32_t num_columns) {
+  if (catalogue_id < 0 || catalogue_id >= TETRIS_N_CATALOGUE) return TETRIS_E_PIECES;
+  return n_placements(catalogue_id, num_columns);
+}
+
+int tetris_hip_desc_init(TetrisDesc* desc, int32_t num_columns, int32_t num_rows, const int32_t* piece_ids,
+                         int32_t n_pieces, const float* direct_by) {
+  return tet::desc_init(desc, num_columns, num_rows, piece_ids, n_pieces, direct_by);
+}
+
+int tetris_hip_reset(const TetrisDesc* desc, void* cols, uint64_t* meta, const uint8_t* reset_mask,
+                     uint8_t* piece_out, uint8_t* n_valid_out, const uint8_t* stream, int32_t* cursor,
+                     int64_t stream_len, int32_t init_bag, uint64_t seed, uint64_t step_idx,
+                     int64_t env_offset, int64_t B, void* hip_stream) {
+  int rc = check_desc(desc);
+  if (rc) return rc;
+  if (!cols || !meta) return TETRIS_E_NULL;
+  if (B <= 0) return TETRIS_E_BATCH;
+  if (stream && (!cursor || stream_len <= 0)) return TETRIS_E_STREAM;
+  ResetParams p;
+  p.cols = cols;
+  p.meta = meta;
+  p.reset_mask = reset_mask;
+  p.piece_out = piece_out;
+  p.n_valid_out = n_valid_out;
+  p.stream = stream;
+  p.cursor = cursor;
+  p.stream_len = stream_len;
+  p.B = B;
+  p.env_offset = env_offset;
+  p.init_bag = init_bag;
+  p.n_pieces = desc->n_pieces;
+  p.key = tet::hash_key(seed, step_idx * 4u + 2u);
+  build_table(desc, &p.tab);
+  return dispatch<LaunchReset>(desc, p, (hipStream_t)hip_stream);
+}
+
+int tetris_hip_step(const TetrisDesc* desc, void* cols, uint64_t* meta, const int32_t* action,
+                    const uint8_t* stream, int32_t* cursor, int64_t stream_len, float* obs, int32_t* reward,
+                    uint8_t* done, uint8_t* lines, uint8_t* n_valid_next, uint8_t* piece_next, uint32_t* status,
+                    int32_t auto_reset, uint64_t seed, uint64_t step_idx, int64_t env_offset, int64_t B,
+                    void* hip_stream) {
+  int rc = check_desc(desc);
+  if (rc) return rc;
+  if (!cols || !meta || !action || !obs || !reward || !done || !lines || !n_valid_next) return TETRIS_E_NULL;
+  if (B <= 0) return TETRIS_E_BATCH;
+  if (stream && (!cursor || stream_len <= 0)) return TETRIS_E_STREAM;
+  StepParams p;
+  p.cols = cols;
+  p.meta = meta;
+  p.action = action;
+  p.stream = stream;
+  p.cursor = cursor;
+  p.stream_len = stream_len;
+  p.obs = obs;
+  p.reward = reward;
+  p.done = done;
+  p.lines = lines;
+  p.n_valid = n_valid_next;
+  p.piece_next = piece_next;
+  p.status = status;
+  p.B = B;
+  p.env_offset = env_offset;
+  p.cfg.R = desc->num_rows;
+  p.cfg.n_pieces = desc->n_pieces;
+  p.cfg.auto_reset = auto_reset;
+  p.cfg.key_step = tet::hash_key(seed, step_idx * 4u + 0u);
+  p.cfg.key_reset = tet::hash_key(seed, step_idx * 4u + 1u);
+  p.cfg.has_direct_by = desc->has_direct_by;
+  for (int i = 0; i < 8; ++i) p.cfg.direct_by[i] = desc->direct_by[i];
+  build_table(desc, &p.tab);
+  return dispatch<LaunchStep>(desc, p, (hipStream_t)hip_stream);
+}
+
+int tetris_hip_afterstates(const TetrisDesc* desc, const void* cols, const uint64_t* meta, float* feats,
+                           uint8_t* n_valid, float* feats_all, uint8_t* n_all, int64_t B, void* hip_stream) {
+  int rc = check_desc(desc);
+  if (rc) return rc;
+  if (!cols || !meta || !feats || !n_valid) return TETRIS_E_NULL;
+  if (B <= 0) return TETRIS_E_BATCH;
+  AfterParams p;
+  p.cols = cols;
+  p.meta = meta;
+  p.feats = feats;
+  p.n_valid = n_valid;
+  p.feats_all = feats_all;
+  p.n_all = n_all;
+  p.B = B;
+  p.R = desc->num_rows;
+  p.a_max = desc->a_max;
+  p.has_direct_by = desc->has_direct_by;
+  for (int i = 0; i < 8; ++i) p.direct_by[i] = desc->direct_by[i];
+  build_table(desc, &p.tab);
+  return dispatch<LaunchAfter>(desc, p, (hipStream_t)hip_stream);
+}
+
+int tetris_hip_refresh(const TetrisDesc* desc, const void* cols, uint64_t* meta, uint8_t* n_valid_out,
+                       int64_t B, void* hip_stream) {
+  int rc = check_desc(desc);
+  if (rc) return rc;
+  if (!cols || !meta) return TETRIS_E_NULL;
+  if (B <= 0) return TETRIS_E_BATCH;
+  RefreshParams p;
+  p.cols = cols;
+  p.meta = meta;
+  p.n_valid_out = n_valid_out;
+  p.B = B;
+  p.R = desc->num_rows;
+  build_table(desc, &p.tab);
+  return dispatch<LaunchRefresh>(desc, p, (hipStream_t)hip_stream);
+}
+
+int tetris_hip_policy_random(const uint8_t* n_valid, int32_t* action, uint64_t seed, uint64_t step_idx,
+                             int64_t env_offset, int64_t B, void* hip_stream) {
+  if (!n_valid || !action) return TETRIS_E_NULL;
+  if (B <= 0) return TETRIS_E_BATCH;
+  const uint32_t key = tet::hash_key(seed, step_idx * 4u + 3u);
+  hipLaunchKernelGGL(policy_random_kernel, grid_for(B), dim3(kBlock), 0, (hipStream_t)hip_stream, n_valid,
+                     action, key, env_offset, B);
+  return (int)hipGetLastError();
+}
+
+int tetris_hip_decode(const TetrisDesc* desc, const void* cols, int8_t* cells, int32_t* heights, int64_t B,
+                      void* hip_stream) {
+  int rc = check_desc(desc);
+  if (rc) return rc;
+  if (!cols) return TETRIS_E_NULL;
+  if (B <= 0) return TETRIS_E_BATCH;
+  const int C = desc->num_columns, rows = desc->num_rows + 4;
+  if (desc->word_bytes == 4)
+    hipLaunchKernelGGL((decode_kernel<uint32_t>), grid_for(B), dim3(kBlock), 0, (hipStream_t)hip_stream,
+                       static_cast<const uint32_t*>(cols), cells, heights, C, rows, B);
+  else
+    hipLaunchKernelGGL((decode_kernel<uint64_t>), grid_for(B), dim3(kBlock), 0, (hipStream_t)hip_stream,
+                       static_cast<const uint64_t*>(cols), cells, heights, C, rows, B);
+  return (int)hipGetLastError();
+}
+
+int tetris_hip_encode(const TetrisDesc* desc, const int8_t* cells, void* cols, int64_t B, void* hip_stream) {
+  int rc = check_desc(desc);
+  if (rc) return rc;
+  if (!cols || !cells) return TETRIS_E_NULL;
+  if (B <= 0) return TETRIS_E_BATCH;
+  const int C = desc->num_columns, rows = desc->num_rows + 4;
+  if (desc->word_bytes == 4)
+    hipLaunchKernelGGL((encode_kernel<uint32_t>), grid_for(B), dim3(kBlock), 0, (hipStream_t)hip_stream, cells,
+                       static_cast<uint32_t*>(cols), C, rows, B);
+  else
+    hipLaunchKernelGGL((encode_kernel<uint64_t>), grid_for(B), dim3(kBlock), 0, (hipStream_t)hip_stream, cells,
+                       static_cast<uint64_t*>(cols), C, rows, B);
+  return (int)hipGetLastError();
+}
+
+}  // extern "C"

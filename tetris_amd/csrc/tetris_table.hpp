@@ -1,0 +1,129 @@
+// tetris_table.hpp -- host-side piece catalogue and per-set table builder.
+// Shared by the C-ABI (tetris_kernels.hip) and the CPU test harness
+// (tests/harness); contains no device code.
+#pragma once
+#include <string.h>
+
+#include "../../include/tetris_hip.h"
+#include "tetris_core.hpp"
+
+namespace tet {
+
+// ---- piece catalogue (tetromino.py:33-576) -------------------
+struct CatOrient { int w; int b[4]; int n[4]; };
+struct CatPiece { int n_orient[2]; CatOrient o[2][2]; };
+
+static const CatPiece kCatalogue[TETRIS_N_CATALOGUE] = {
+    /* Straight  :44-57, :60-74 */
+    {{1, 1}, {{{1, {0}, {4}}}, {{4, {0, 0, 0, 0}, {1, 1, 1, 1}}}}},
+    /* Square    :90-103 */
+    {{1, 0}, {{{2, {0, 0}, {2, 2}}}}},
+    /* SnakeR    :120-135, :138-153 */
+    {{1, 1}, {{{3, {0, 0, 1}, {1, 2, 1}}}, {{2, {1, 0}, {2, 2}}}}},
+    /* ThreeLine :168-181, :184-198 */
+    {{1, 1}, {{{1, {0}, {3}}}, {{3, {0, 0, 0}, {1, 1, 1}}}}},
+    /* ThreeL    :214-247, :250-281 */
+    {{2, 2}, {{{2, {0, 0}, {1, 2}}, {2, {0, 1}, {2, 1}}}, {{2, {1, 0}, {1, 2}}, {2, {0, 0}, {2, 1}}}}},
+    /* SnakeL    :297-312, :315-330 */
+    {{1, 1}, {{{3, {1, 0, 0}, {1, 2, 1}}}, {{2, {0, 1}, {2, 2}}}}},
+    /* T         :346-378, :381-413 */
+    {{2, 2}, {{{3, {0, 0, 0}, {1, 2, 1}}, {3, {1, 0, 1}, {1, 2, 1}}}, {{2, {1, 0}, {1, 3}}, {2, {0, 1}, {3, 1}}}}},
+    /* RCorner   :429-460, :463-494 */
+    {{2, 2}, {{{3, {0, 0, 0}, {1, 1, 2}}, {3, {0, 1, 1}, {2, 1, 1}}}, {{2, {2, 0}, {1, 3}}, {2, {0, 0}, {3, 1}}}}},
+    /* LCorner   :509-540, :543-575 */
+    {{2, 2}, {{{3, {0, 0, 0}, {2, 1, 1}}, {3, {1, 1, 0}, {1, 1, 2}}}, {{2, {0, 2}, {3, 1}}, {2, {0, 0}, {1, 3}}}}},
+};
+
+inline uint32_t pack_orient(const CatOrient& o) {
+  int H = 0;
+  uint32_t d = (uint32_t)o.w;
+  for (int j = 0; j < o.w; ++j) {
+    if (o.b[j] + o.n[j] > H) H = o.b[j] + o.n[j];
+    d |= (uint32_t)o.b[j] << (6 + 5 * j);
+    d |= (uint32_t)o.n[j] << (8 + 5 * j);
+  }
+  d |= (uint32_t)H << 3;
+  d |= 1u << 31;
+  return d;
+}
+
+inline int n_placements(int pid, int C) {
+  const CatPiece& p = kCatalogue[pid];
+  int total = 0;
+  for (int l = 0; l < 2; ++l)
+    if (p.n_orient[l] > 0 && C - p.o[l][0].w + 1 > 0) total += (C - p.o[l][0].w + 1) * p.n_orient[l];
+  return total;
+}
+
+inline void build_table(const TetrisDesc* d, SetTable* t) {
+  memset(t, 0, sizeof(*t));
+  const int C = d->num_columns;
+  for (int i = 0; i < d->n_pieces; ++i) {
+    const CatPiece& p = kCatalogue[d->piece_ids[i]];
+    uint64_t full = 0;
+    for (int l = 0; l < 2; ++l)
+      for (int oi = 0; oi < p.n_orient[l]; ++oi) {
+        t->orient[i][l * 2 + oi] = pack_orient(p.o[l][oi]);
+        for (int c = 0; c + p.o[l][oi].w <= C; ++c) full |= 1ull << (l * 2 * C + 2 * c + oi);
+      }
+    t->fullmask[i] = full;
+  }
+}
+
+
+// num_columns values the kernels are instantiated for (one place for the
+// library, the dispatch switch and the CPU test harness)
+#define TET_COLUMNS(X) X(6) X(8) X(10)
+
+inline bool columns_supported(int C) {
+  switch (C) {
+#define TET_X(CC) case CC:
+    TET_COLUMNS(TET_X)
+#undef TET_X
+    return true;
+    default:
+      return false;
+  }
+}
+
+inline int check_desc(const TetrisDesc* d) {
+  if (!d) return TETRIS_E_NULL;
+  if (d->abi_version != TETRIS_HIP_ABI_VERSION) return TETRIS_E_DESC;
+  if (d->num_rows < 4 || d->num_rows > 59) return TETRIS_E_ROWS;
+  if (d->word_bytes != ((d->num_rows + 4 <= 31) ? 4 : 8)) return TETRIS_E_DESC;
+  if (d->n_pieces < 1 || d->n_pieces > TETRIS_MAX_PIECES) return TETRIS_E_PIECES;
+  for (int i = 0; i < d->n_pieces; ++i)
+    if (d->piece_ids[i] < 0 || d->piece_ids[i] >= TETRIS_N_CATALOGUE) return TETRIS_E_PIECES;
+  return TETRIS_OK;
+}
+
+
+// game.py:21-51 constructor arguments -> descriptor
+inline int desc_init(TetrisDesc* desc, int32_t num_columns, int32_t num_rows, const int32_t* piece_ids,
+                     int32_t n_pieces, const float* direct_by) {
+  if (!desc || !piece_ids) return TETRIS_E_NULL;
+  memset(desc, 0, sizeof(*desc));
+  if (!columns_supported(num_columns)) return TETRIS_E_COLUMNS;
+  if (num_rows < 4 || num_rows > 59) return TETRIS_E_ROWS;
+  if (n_pieces < 1 || n_pieces > TETRIS_MAX_PIECES) return TETRIS_E_PIECES;
+  desc->abi_version = TETRIS_HIP_ABI_VERSION;
+  desc->num_columns = num_columns;
+  desc->num_rows = num_rows;
+  desc->word_bytes = (num_rows + 4 <= 31) ? 4 : 8;
+  desc->n_pieces = n_pieces;
+  int amax = 0;
+  for (int i = 0; i < n_pieces; ++i) {
+    if (piece_ids[i] < 0 || piece_ids[i] >= TETRIS_N_CATALOGUE) return TETRIS_E_PIECES;
+    desc->piece_ids[i] = piece_ids[i];
+    int n = n_placements(piece_ids[i], num_columns);
+    if (n > amax) amax = n;
+  }
+  desc->a_max = amax;
+  if (direct_by) {
+    desc->has_direct_by = 1;
+    for (int i = 0; i < 8; ++i) desc->direct_by[i] = direct_by[i];
+  }
+  return TETRIS_OK;
+}
+
+}  // namespace tet

@@ -1,0 +1,253 @@
+"""VecTetris: a batch of placement-level Tetris envs resident in HBM.
+
+The batched counterpart of the reference's ``game.Tetris`` (game.py:8-100):
+``reset() / get_after_states() / step(actions)`` for B envs in lockstep.  All
+state lives in PyTorch-ROCm tensors; every method enqueues one HIP kernel of
+``libtetris_hip.so`` on the current stream through the C-ABI
+(include/tetris_hip.h).  PyTorch is plumbing (memory + streams) only.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from .tetromino import CATALOGUE, Tetromino, resolve_pieces
+
+
+def _ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+class VecTetris:
+    """B independent envs with the semantics of game.Tetris.
+
+    Parameters mirror ``Tetris(num_columns, num_rows, feature_directions=None)``
+    (game.py:21-23) plus the batch knobs:
+
+    batch_size   number of envs
+    device       a CUDA (ROCm) device
+    pieces       'default' (game.py:38-39), 'standard7' (game.py:41-47) or names
+    auto_reset   reset finished envs inside the step kernel (game.py:53-63)
+    seed         seed of the counter-based device bag
+    piece_stream optional uint8 [L, B]: replay these list indices instead of the
+                 device bag (parity runs against a recorded NumPy stream)
+    env_offset   global index of env 0 (shards of one logical batch draw the
+                 same pieces as the unsharded batch)
+
+    ``step`` returns views of buffers that the next ``step`` overwrites.
+    """
+
+    def __init__(self, num_columns, num_rows, batch_size, device="cuda", pieces="default", auto_reset=False,
+                 seed=0, feature_directions=None, piece_stream=None, env_offset=0):
+        self._lib = _lib.load()
+        self.device = torch.device(device)
+        if self.device.type != self._lib.device_type:
+            raise ValueError("VecTetris needs a %s device (got %s): the env only exists as HIP kernels"
+                             % (self._lib.device_type, self.device))
+        if self.device.type == "cuda" and self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        self.num_columns, self.num_rows, self.batch_size = int(num_columns), int(num_rows), int(batch_size)
+        self.piece_names = resolve_pieces(pieces)
+        self.tetrominos = [Tetromino(n, i, self.num_columns) for i, n in enumerate(self.piece_names)]
+        self.auto_reset = bool(auto_reset)
+        self.seed = int(seed)
+        self.env_offset = int(env_offset)
+        self.feature_directions = feature_directions
+        self.loss_reward, self.timestep_reward = -100, -1  # game.py:34-35 (baked into the kernel)
+
+        ids = (ctypes.c_int32 * len(self.piece_names))(*[CATALOGUE.index(n) for n in self.piece_names])
+        dirs = None
+        if feature_directions is not None:
+            fd = np.asarray(feature_directions, dtype=np.float32)
+            if fd.shape != (8,):
+                raise ValueError("feature_directions must have 8 entries")
+            dirs = (ctypes.c_float * 8)(*fd.tolist())
+        self.desc = _lib.TetrisDesc()
+        self._lib.check(self._lib.desc_init(ctypes.byref(self.desc), self.num_columns, self.num_rows, ids,
+                                            len(self.piece_names), dirs), "tetris_hip_desc_init")
+        if self.batch_size <= 0:
+            raise ValueError("batch_size must be positive")
+        self.a_max = int(self.desc.a_max)
+        self.stored_rows = self.num_rows + 4
+        self.word_dtype = torch.int32 if self.desc.word_bytes == 4 else torch.int64
+
+        B, dev = self.batch_size, self.device
+        with torch.device(dev):
+            self.cols = torch.zeros((self.num_columns, B), dtype=self.word_dtype)  # plane-major bitboards
+            self.meta = torch.zeros(B, dtype=torch.int64)
+            self.obs = torch.zeros((B, 8), dtype=torch.float32)
+            self.reward = torch.zeros(B, dtype=torch.int32)
+            self._done = torch.zeros(B, dtype=torch.uint8)
+            self.lines = torch.zeros(B, dtype=torch.uint8)
+            self.n_valid = torch.zeros(B, dtype=torch.uint8)
+            self.piece = torch.zeros(B, dtype=torch.uint8)
+            self.status = torch.zeros(4, dtype=torch.int32)
+            self._action = torch.zeros(B, dtype=torch.int32)
+        self.done = self._done.view(torch.bool)
+        self._stream = None
+        self._cursor = None
+        if piece_stream is not None:
+            ps = torch.as_tensor(piece_stream, dtype=torch.uint8)
+            if ps.dim() != 2 or ps.shape[1] != B:
+                raise ValueError("piece_stream must be [L, batch_size]")
+            self._stream = ps.to(dev).contiguous()
+            self._cursor = torch.zeros(B, dtype=torch.int32, device=dev)
+        self._feats = None
+        self._feats_all = None
+        self._n_all = None
+        self.step_idx = 0
+        self.reset(init_bag=True)
+
+    # -- plumbing -----------------------------------------------------------------
+    def _hip_stream(self):
+        if self.device.type == "cuda":
+            return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        return None
+
+    def _stream_args(self):
+        if self._stream is None:
+            return None, None, 0
+        return _ptr(self._stream), _ptr(self._cursor), int(self._stream.shape[0])
+
+    # -- Tetris.reset (game.py:53-63) -----------------------------------------------
+    def reset(self, mask=None, init_bag=False):
+        """Reset every env (or those where ``mask`` is true).  The bag is kept
+        unless ``init_bag`` (the reference bag survives reset: game.py:50)."""
+        m = None
+        if mask is not None:
+            m = torch.as_tensor(mask, device=self.device).to(torch.uint8).contiguous()
+            if m.shape != (self.batch_size,):
+                raise ValueError("mask must be [batch_size]")
+        s, c, n = self._stream_args()
+        rc = self._lib.reset(ctypes.byref(self.desc), _ptr(self.cols), _ptr(self.meta), _ptr(m), _ptr(self.piece),
+                             _ptr(self.n_valid), s, c, n, int(bool(init_bag)), self.seed, self.step_idx,
+                             self.env_offset, self.batch_size, self._hip_stream())
+        self._lib.check(rc, "tetris_hip_reset")
+
+    # -- Tetris.get_after_states (game.py:67-80) --------------------------------------
+    def get_after_states(self, include_terminal=False):
+        """BCTS features of every placement of the current piece.
+
+        Returns ``(features [B, a_max, 8] float32, n_valid [B] uint8)``; row k of
+        env i is its k-th non-terminal placement (= action k), rows >= n_valid
+        are zero.  With ``include_terminal`` also ``(features_all, n_all)`` in
+        raw enumeration order (game.py:74-78)."""
+        B = self.batch_size
+        if self._feats is None:
+            self._feats = torch.empty((B, self.a_max, 8), dtype=torch.float32, device=self.device)
+            self._nv_after = torch.empty(B, dtype=torch.uint8, device=self.device)
+        fa = na = None
+        if include_terminal:
+            if self._feats_all is None:
+                self._feats_all = torch.empty((B, self.a_max, 8), dtype=torch.float32, device=self.device)
+                self._n_all = torch.empty(B, dtype=torch.uint8, device=self.device)
+            fa, na = self._feats_all, self._n_all
+        rc = self._lib.afterstates(ctypes.byref(self.desc), _ptr(self.cols), _ptr(self.meta), _ptr(self._feats),
+                                   _ptr(self._nv_after), _ptr(fa), _ptr(na), B, self._hip_stream())
+        self._lib.check(rc, "tetris_hip_afterstates")
+        if include_terminal:
+            return self._feats, self._nv_after, fa, na
+        return self._feats, self._nv_after
+
+    # -- Tetris.step (game.py:82-92) ------------------------------------------------------
+    def step(self, action):
+        """``action`` [B] = index into each env's non-terminal placements.
+
+        Returns ``(obs [B,8] f32, reward [B] i32, done [B] bool, lines [B] u8)``.
+        Out-of-range actions leave that env untouched and are counted; call
+        :meth:`check` to turn them into the reference's IndexError."""
+        a = torch.as_tensor(action, device=self.device)
+        if a.shape != (self.batch_size,):
+            raise ValueError("action must be [batch_size]")
+        if a.dtype != torch.int32 or not a.is_contiguous():
+            a = a.to(torch.int32).contiguous()
+        s, c, n = self._stream_args()
+        rc = self._lib.step(ctypes.byref(self.desc), _ptr(self.cols), _ptr(self.meta), _ptr(a), s, c, n,
+                            _ptr(self.obs), _ptr(self.reward), _ptr(self._done), _ptr(self.lines), _ptr(self.n_valid),
+                            _ptr(self.piece), _ptr(self.status), int(self.auto_reset), self.seed, self.step_idx,
+                            self.env_offset, self.batch_size, self._hip_stream())
+        self._lib.check(rc, "tetris_hip_step")
+        self.step_idx += 1
+        return self.obs, self.reward, self.done, self.lines
+
+    def random_actions(self, out=None):
+        """Uniform random valid action per env (the random-rollout policy)."""
+        out = self._action if out is None else out
+        rc = self._lib.policy_random(_ptr(self.n_valid), _ptr(out), self.seed, self.step_idx, self.env_offset,
+                                     self.batch_size, self._hip_stream())
+        self._lib.check(rc, "tetris_hip_policy_random")
+        return out
+
+    # -- inspection ---------------------------------------------------------------------------
+    def boards(self):
+        """State.representation for every env: int8 [B, R+4, C], row 0 = bottom."""
+        cells = torch.empty((self.batch_size, self.stored_rows, self.num_columns), dtype=torch.int8,
+                            device=self.device)
+        rc = self._lib.decode(ctypes.byref(self.desc), _ptr(self.cols), _ptr(cells), None, self.batch_size,
+                              self._hip_stream())
+        self._lib.check(rc, "tetris_hip_decode")
+        return cells
+
+    def heights(self):
+        """State.lowest_free_rows for every env: int32 [B, C]."""
+        h = torch.empty((self.batch_size, self.num_columns), dtype=torch.int32, device=self.device)
+        rc = self._lib.decode(ctypes.byref(self.desc), _ptr(self.cols), None, _ptr(h), self.batch_size,
+                              self._hip_stream())
+        self._lib.check(rc, "tetris_hip_decode")
+        return h
+
+    def set_boards(self, cells, piece=None):
+        """Overwrite the boards (int8 [B, R+4, C]) and optionally the current
+        pieces (list indices [B]); the valid masks are recomputed."""
+        cells = torch.as_tensor(cells, device=self.device).to(torch.int8).contiguous()
+        if cells.shape != (self.batch_size, self.stored_rows, self.num_columns):
+            raise ValueError("cells must be [B, num_rows + 4, num_columns]")
+        rc = self._lib.encode(ctypes.byref(self.desc), _ptr(cells), _ptr(self.cols), self.batch_size,
+                              self._hip_stream())
+        self._lib.check(rc, "tetris_hip_encode")
+        if piece is not None:
+            p = torch.as_tensor(piece, device=self.device).to(torch.int64)
+            if p.shape != (self.batch_size,):
+                raise ValueError("piece must be [batch_size]")
+            keep = ~(torch.tensor(15, dtype=torch.int64, device=self.device) << 48)
+            self.meta.copy_((self.meta & keep) | (p << 48))
+            self.piece.copy_(p.to(torch.uint8))
+        self.refresh()
+
+    def refresh(self):
+        """Recompute valid masks / n_valid from (cols, piece) after a manual edit."""
+        rc = self._lib.refresh(ctypes.byref(self.desc), _ptr(self.cols), _ptr(self.meta), _ptr(self.n_valid),
+                               self.batch_size, self._hip_stream())
+        self._lib.check(rc, "tetris_hip_refresh")
+
+    def stats(self):
+        """Counters accumulated by the step kernel (synchronises)."""
+        s = self.status.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+        return dict(invalid=int(s[0]), episodes=int(s[1]), lines=int(s[2]), steps=int(s[3]))
+
+    def check(self):
+        """Raise IndexError if any step so far received an out-of-range action
+        (game.py:83 raises it immediately; the batch path reports lazily)."""
+        n = self.stats()["invalid"]
+        if n:
+            raise IndexError("%d out-of-range actions were passed to step()" % n)
+
+    # -- checkpoint / snapshot --------------------------------------------------------------------
+    def state_dict(self):
+        d = dict(cols=self.cols.clone(), meta=self.meta.clone(), n_valid=self.n_valid.clone(),
+                 piece=self.piece.clone(), status=self.status.clone(), step_idx=self.step_idx, seed=self.seed,
+                 num_columns=self.num_columns, num_rows=self.num_rows, pieces=list(self.piece_names))
+        if self._cursor is not None:
+            d["cursor"] = self._cursor.clone()
+        return d
+
+    def load_state_dict(self, d):
+        if (d["num_columns"], d["num_rows"], list(d["pieces"])) != (self.num_columns, self.num_rows,
+                                                                     list(self.piece_names)):
+            raise ValueError("state_dict belongs to a different env configuration")
+        for k in ("cols", "meta", "n_valid", "piece", "status"):
+            getattr(self, k).copy_(d[k])
+        if self._cursor is not None and "cursor" in d:
+            self._cursor.copy_(d["cursor"])
+        self.step_idx, self.seed = int(d["step_idx"]), int(d["seed"])
