@@ -43,6 +43,7 @@ def cpu_baseline(C, R, pieces, seconds=12.0):
         cores = len(os.sched_getaffinity(0))
     except Exception:
         pass
+    cores = min(cores, int(os.environ.get("TETRIS_BENCH_CPU_THREADS", "16")))  # a 1-GPU box's CPU share
     B = 2048 * cores
     env = orc.OracleVecEnv(C, R, B, pieces=pieces, auto_reset=True, seed=0, nthreads=cores)
     rng = np.random.default_rng(0)
@@ -117,7 +118,7 @@ def main():
         a = env.random_actions()
         env.step(a)
         if world > 1 and (t + 1) % args.gather_every == 0:
-            gather.gather_counters(env.status)
+            gather.gather_counters(env.totals())
 
     for t in range(args.warmup):
         one_step(t)
@@ -133,7 +134,7 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    totals = gather.gather_counters(env.status).cpu().tolist()
+    totals = gather.gather_counters(env.totals()).cpu().tolist()
 
     # step-kernel time alone, HIP events on the launch stream (torch's current stream)
     n_prof = 50

@@ -75,8 +75,11 @@ typedef struct TetrisDesc {
   float direct_by[8];
 } TetrisDesc;
 
-/* counters the kernels add to (uint32[4], caller zeroes them) */
+/* Counters the step kernel adds to.  To stay free of atomics every wavefront
+ * owns one slot of 4 uint32: status is uint32[tetris_hip_status_words(B)] =
+ * [n_waves][4], zeroed by the caller; the totals are the column sums. */
 enum { TETRIS_STATUS_INVALID = 0, TETRIS_STATUS_EPISODES = 1, TETRIS_STATUS_LINES = 2, TETRIS_STATUS_STEPS = 3 };
+int64_t tetris_hip_status_words(int64_t B);
 
 int tetris_hip_version(void);
 const char* tetris_hip_error_string(int code);
@@ -120,7 +123,7 @@ int tetris_hip_reset(const TetrisDesc* desc, void* cols, uint64_t* meta, const u
  *  n_valid_next : uint8[B]        non-terminal placements of the new piece
  *                                 (after auto-reset: of the fresh episode)
  *  piece_next   : uint8[B] or NULL  list index of the new current piece
- *  status       : uint32[4] or NULL counters (TETRIS_STATUS_*), atomically added
+ *  status       : uint32[tetris_hip_status_words(B)] or NULL: per-wave counters (TETRIS_STATUS_*)
  * An out-of-range action (game.py:83 raises IndexError) leaves that env
  * untouched, writes obs = 0, reward = 0, lines = 0 and counts it in
  * status[TETRIS_STATUS_INVALID].

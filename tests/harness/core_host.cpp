@@ -58,12 +58,13 @@ void step_impl(const TetrisDesc* desc, void* cols_, uint64_t* meta, const int32_
     lines[i] = (uint8_t)out.lines;
     n_valid[i] = (uint8_t)out.n_valid;
     if (piece_next) piece_next[i] = (uint8_t)out.piece;
-    if (status) {
-      status[TETRIS_STATUS_INVALID] += out.invalid;
+    if (status) {  // one slot of 4 counters per 64 envs (= per wavefront on the GPU)
+      uint32_t* slot = status + (i >> 6) * 4;
+      slot[TETRIS_STATUS_INVALID] += out.invalid;
       if (!out.invalid) {
-        status[TETRIS_STATUS_EPISODES] += out.done;
-        status[TETRIS_STATUS_LINES] += out.lines;
-        status[TETRIS_STATUS_STEPS] += 1;
+        slot[TETRIS_STATUS_EPISODES] += out.done;
+        slot[TETRIS_STATUS_LINES] += out.lines;
+        slot[TETRIS_STATUS_STEPS] += 1;
       }
     }
   }
@@ -247,6 +248,8 @@ int tetris_host_policy_random(const uint8_t* n_valid, int32_t* action, uint64_t 
 }
 
 int tetris_host_version(void) { return TETRIS_HIP_ABI_VERSION; }
+
+int64_t tetris_host_status_words(int64_t B) { return B <= 0 ? 0 : 4 * (((B + 255) / 256) * 4); }
 
 int tetris_host_n_placements(int32_t catalogue_id, int32_t num_columns) {
   if (catalogue_id < 0 || catalogue_id >= TETRIS_N_CATALOGUE) return TETRIS_E_PIECES;

@@ -30,14 +30,16 @@ __device__ __forceinline__ void stage_table(SetTable& lds, const SetTable& arg) 
   __syncthreads();
 }
 
-__device__ __forceinline__ void wave_count(uint32_t* counter, int value_bits, int v) {
-  // sum of small per-lane integers through ballots; one atomic per wave, only if nonzero
+// Per-wave counters without atomics: same-address atomics from 16k waves serialise
+// at ~12 ns each (measured: 430 us per launch), so every wave owns one 16-byte slot
+// of `status` and lane 0 read-modify-writes it (launches are stream-ordered).
+__device__ __forceinline__ unsigned wave_sum(int value_bits, int v) {
   unsigned total = 0;
   for (int b = 0; b < value_bits; ++b) {
     unsigned long long m = __ballot((v >> b) & 1);
     total += (unsigned)__popcll(m) << b;
   }
-  if (total != 0 && (threadIdx.x & 63) == 0) atomicAdd(counter, total);
+  return total;
 }
 
 struct StepParams {
@@ -103,10 +105,20 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const StepParams p) {
     if (p.piece_next) p.piece_next[i] = (uint8_t)out.piece;
   }
   if (p.status) {
-    wave_count(p.status + TETRIS_STATUS_INVALID, 1, invalid);
-    wave_count(p.status + TETRIS_STATUS_EPISODES, 1, done);
-    wave_count(p.status + TETRIS_STATUS_LINES, 3, lines);
-    wave_count(p.status + TETRIS_STATUS_STEPS, 1, (live && !invalid) ? 1 : 0);
+    const unsigned n_inv = wave_sum(1, invalid);
+    const unsigned n_done = wave_sum(1, done);
+    const unsigned n_lines = wave_sum(3, lines);
+    const unsigned n_steps = wave_sum(1, (live && !invalid) ? 1 : 0);
+    if ((threadIdx.x & 63) == 0) {
+      const int64_t wave = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+      uint4* slot = reinterpret_cast<uint4*>(p.status) + wave;
+      uint4 v = *slot;
+      v.x += n_inv;
+      v.y += n_done;
+      v.z += n_lines;
+      v.w += n_steps;
+      *slot = v;
+    }
   }
 }
 
@@ -378,6 +390,11 @@ int tetris_hip_supported_columns(int32_t* out, int cap) {
   TET_COLUMNS(X)
 #undef X
   return n;
+}
+
+int64_t tetris_hip_status_words(int64_t B) {
+  if (B <= 0) return 0;
+  return 4 * (((B + kBlock - 1) / kBlock) * (kBlock / 64));
 }
 
 int tetris_hip_n_placements(int32_t catalogue_id, int32_t num_columns) {

@@ -58,9 +58,9 @@ class DoneGather:
         flags = torch.stack([unpack_done_bits(out[r], self.local_envs) for r in range(out.shape[0])])
         return torch.nonzero(flags.flatten(), as_tuple=False).flatten()
 
-    def gather_counters(self, status):
-        """Sum of the step kernel's status counters over all ranks -> int64 [4]."""
-        s = (status.to(torch.int64) & 0xFFFFFFFF).clone()
+    def gather_counters(self, totals):
+        """Sum of the env's counters (VecTetris.totals(), int64 [4]) over all ranks."""
+        s = totals.clone()
         if self.world > 1:
             dist.all_reduce(s, op=dist.ReduceOp.SUM, group=self.group)
         return s

@@ -82,7 +82,7 @@ class VecTetris:
             self.lines = torch.zeros(B, dtype=torch.uint8)
             self.n_valid = torch.zeros(B, dtype=torch.uint8)
             self.piece = torch.zeros(B, dtype=torch.uint8)
-            self.status = torch.zeros(4, dtype=torch.int32)
+            self.status = torch.zeros(int(self._lib.status_words(B)), dtype=torch.int32)  # [n_waves, 4]
             self._action = torch.zeros(B, dtype=torch.int32)
         self.done = self._done.view(torch.bool)
         self._stream = None
@@ -221,9 +221,13 @@ class VecTetris:
                                self.batch_size, self._hip_stream())
         self._lib.check(rc, "tetris_hip_refresh")
 
+    def totals(self):
+        """int64 [4] device tensor: (invalid, episodes, lines, steps) summed over the per-wave slots."""
+        return (self.status.view(-1, 4).to(torch.int64) & 0xFFFFFFFF).sum(dim=0)
+
     def stats(self):
         """Counters accumulated by the step kernel (synchronises)."""
-        s = self.status.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+        s = self.totals().cpu().numpy()
         return dict(invalid=int(s[0]), episodes=int(s[1]), lines=int(s[2]), steps=int(s[3]))
 
     def check(self):
