@@ -24,9 +24,10 @@
  *          (game.py:56, state.py:27-30).  Word = uint32 if R+4 <= 31,
  *          uint64 if R+4 <= 63 (TetrisDesc.word_bytes).
  *  meta  : uint64[B] per-env control word:
- *            bits  0-47 valid mask over static slots s = L*2C + 2c + o
- *                       (ascending s = reference enumeration order; the k-th
- *                       set bit is action k, game.py:69,83)
+ *            bits  0-47 valid mask over static slots s = 4c + 2L + o (column c,
+ *                       loop L, orientation o of tetromino.py's enumeration);
+ *                       action k (game.py:69,83) is the k-th set bit of the
+ *                       L = 0 slots followed by the L = 1 slots
  *            bits 48-51 current piece (index into the piece list, game.py:38-39)
  *            bits 52-63 bag: list indices still to be drawn (tetromino.py:12-22)
  */
@@ -42,7 +43,7 @@ extern "C" {
 #define TETRIS_HIP_ABI_VERSION 1
 
 #define TETRIS_MAX_PIECES 12
-#define TETRIS_MAX_COLUMNS 12
+#define TETRIS_MAX_COLUMNS 10
 #define TETRIS_N_CATALOGUE 9
 
 /* catalogue ids: class order of tetromino.py:33-576 */

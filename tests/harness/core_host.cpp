@@ -109,9 +109,7 @@ void refresh_impl(const TetrisDesc* desc, const void* cols_, uint64_t* meta, uin
     for (int c = 0; c < C; ++c) col[c] = cols[(int64_t)c * B + i];
     tet::heights_of<W, C>(col, h);
     const int piece = tet::meta_piece(meta[i]);
-    uint32_t d4[4];
-    for (int k = 0; k < 4; ++k) d4[k] = tab.orient[piece][k];
-    const uint64_t mask = tet::valid_mask<W, C>(col, h, d4, tab.fullmask[piece], desc->num_rows);
+    const uint64_t mask = tet::valid_mask<W, C>(col, h, tab.orient[piece], tab.fullmask[piece], desc->num_rows);
     meta[i] = tet::meta_pack(mask, piece, tet::meta_bag(meta[i]));
     if (n_valid_out) n_valid_out[i] = (uint8_t)tet::popc(mask);
   }
@@ -138,12 +136,11 @@ void after_impl(const TetrisDesc* desc, const void* cols_, const uint64_t* meta,
     if (out_all) memset(out_all, 0, sizeof(float) * a_max * 8);
     const int nv = tet::popc(valid), na = tet::popc(full);
     for (int lo = 0; lo < 4; ++lo) {
-      const tet::Orient o = tet::unpack_orient(tab.orient[piece][lo]);
+      const tet::Orient o = tet::unpack_orient(tab.orient[piece][lo][0]);
       if (!o.exists) continue;
       for (int c = 0; c < C; ++c) {
-        const int s = (lo >> 1) * 2 * C + 2 * c + (lo & 1);
+        const int s = 4 * c + lo;
         if (!((full >> s) & 1)) continue;
-        const uint64_t below = (1ull << s) - 1;
         W nb[C];
         W pbits[4];
         int nh[C];
@@ -161,8 +158,8 @@ void after_impl(const TetrisDesc* desc, const void* cols_, const uint64_t* meta,
           n_valid[i] = 255;
           return;
         }
-        if (out_all) memcpy(out_all + tet::popc(full & below) * 8, f, sizeof(f));
-        if ((valid >> s) & 1) memcpy(out_valid + tet::popc(valid & below) * 8, f, sizeof(f));
+        if (out_all) memcpy(out_all + tet::row_of_slot(full, s) * 8, f, sizeof(f));
+        if ((valid >> s) & 1) memcpy(out_valid + tet::row_of_slot(valid, s) * 8, f, sizeof(f));
       }
     }
     n_valid[i] = (uint8_t)nv;

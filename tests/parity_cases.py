@@ -190,3 +190,56 @@ def full_size_properties(device, B=1 << 20, steps=60, R=20):
     for c in range(1, 10):
         full = full & env.cols[c]
     assert not full.any()
+
+
+def mask_rescue_stress(device, orc, n_boards=1500, R=20, C=10, seed=0):
+    """Near-top boards whose rows R-3..R-1 miss only a few cells: the placements that poke
+    above row R-1 are valid only if their line clear pulls the stack back (state.py:33 before
+    :36).  Valid masks / n_valid / feature rows vs the oracle for all nine pieces."""
+    from tetris_amd import VecTetris
+    from tetris_amd.tetromino import CATALOGUE
+    rng = np.random.default_rng(seed)
+    rows = R + 4
+    cells = np.zeros((n_boards, rows, C), np.int8)
+    for b in range(n_boards):
+        hts = rng.integers(R - 5, R + 1, size=C)
+        for c in range(C):
+            hc = int(hts[c])
+            colv = (rng.random(hc) > 0.15).astype(np.int8)
+            if hc:
+                colv[hc - 1] = 1
+            cells[b, :hc, c] = colv
+        # make 1-3 of the top rows nearly full: missing run of width 1..4
+        for r in rng.choice(np.arange(R - 4, R), size=rng.integers(1, 4), replace=False):
+            w = int(rng.integers(1, 5))
+            c0 = int(rng.integers(0, C - w + 1))
+            cells[b, r, :] = 1
+            cells[b, r, c0:c0 + w] = 0
+            # columns in the gap must not have cells above the gap row (heights stay consistent)
+            cells[b, r:, c0:c0 + w] = 0
+        for r in range(rows):  # no full rows in a reachable board
+            if cells[b, r].sum() == C:
+                cells[b, r, rng.integers(0, C)] = 0
+        # cells above a removed cell may now float: that is fine for the reference semantics
+        # as long as heights are recomputed from the board (State(lowest_free_rows=None))
+        cells[b, R:, :] = 0
+    desc = orc.make_desc(C, R, list(CATALOGUE))
+    env = VecTetris(C, R, n_boards, device=device, pieces=list(CATALOGUE))
+    n_rescued = 0
+    for pi, name in enumerate(CATALOGUE):
+        env.set_boards(cells, piece=np.full(n_boards, pi))
+        f, nv, fa, na = env.get_after_states(include_terminal=True)
+        f, nv, fa, na = f.cpu().numpy(), nv.cpu().numpy(), fa.cpu().numpy(), na.cpu().numpy()
+        env_nv = env.n_valid.cpu().numpy()
+        for b in range(n_boards):
+            out = orc.placements(desc, cells[b], name)
+            term = out["terminal"].astype(bool)
+            assert na[b] == len(term)
+            assert nv[b] == int((~term).sum()) == env_nv[b], (name, b, nv[b], int((~term).sum()), env_nv[b])
+            np.testing.assert_array_equal(fa[b, :na[b]], out["feats"])
+            np.testing.assert_array_equal(f[b, :nv[b]], out["feats"][~term])
+            # rescued = poked above R-1 before the clear yet non-terminal after it
+            n_rescued += int(((out["anchor_row"] + 0 >= 0) & (~term) & (out["n_cleared"] > 0) &
+                              (out["heights"].max(axis=1) + out["n_cleared"] > R)).sum())
+    assert n_rescued > 50, n_rescued
+    return n_rescued

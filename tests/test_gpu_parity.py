@@ -43,3 +43,8 @@ def test_full_size_properties():
 def test_tall_board_cfg5_properties():
     """BASELINE config 5: 10x40 (u64 columns) + auto-reset, size-independent invariants at 1M envs."""
     pc.full_size_properties(DEV, R=40, steps=100)
+
+
+def test_mask_rescue_stress(orc):
+    pc.mask_rescue_stress(DEV, orc, n_boards=1500)
+    pc.mask_rescue_stress(DEV, orc, n_boards=500, R=40, seed=1)

@@ -33,3 +33,9 @@ def test_sharding_equals_single_batch(host_backend):
 def test_properties(host_backend):
     pc.full_size_properties(DEV, B=4096, steps=60)
     pc.full_size_properties(DEV, B=2048, R=40, steps=100)
+
+
+def test_mask_rescue_stress(host_backend, orc):
+    pc.mask_rescue_stress(DEV, orc, n_boards=600)
+    pc.mask_rescue_stress(DEV, orc, n_boards=200, R=40, seed=1)
+    pc.mask_rescue_stress(DEV, orc, n_boards=200, R=10, C=6, seed=2)

@@ -19,10 +19,16 @@
 #define TET_HD inline
 #endif
 
+// Experiment switch for tools/ablate.py (timing-only builds with parts of the
+// step removed; results are wrong when nonzero).  Always 0 in the product build.
+#ifndef TET_ABLATE
+#define TET_ABLATE 0
+#endif
+
 namespace tet {
 
 constexpr int kMaxPieces = 12;   // pieces in one set (bag is 12 bits of meta)
-constexpr int kMaxCols = 12;     // 4*C slot bits must fit the 48-bit mask
+constexpr int kMaxCols = 10;     // 4*C slot bits fit the 48-bit mask; valid_mask packs 3 bits x C into 32
 constexpr int kNumCatalogue = 9;
 
 // ---- packed orientation descriptor --------------------------------------
@@ -49,8 +55,10 @@ TET_HD Orient unpack_orient(uint32_t d) {
 }
 
 // ---- meta word ------------------------------------------------------------
-// bits 0-47  valid mask over static slots s = L*2C + 2c + o (ascending s is
-//            the reference enumeration order: loop, column, orientation)
+// bits 0-47  valid mask over static slots s = 4c + 2L + o.  The reference
+//            enumerates (loop L, column c, orientation o) in that order, so
+//            action k is the k-th set bit of the L = 0 slots followed by the
+//            L = 1 slots, each taken in ascending bit order (slot_of_action)
 // bits 48-51 current piece (list index, game.py:38-39)
 // bits 52-63 bag: list indices still to be drawn (tetromino.py:12-22)
 constexpr uint64_t kMaskBits = (1ull << 48) - 1;
@@ -124,10 +132,34 @@ TET_HD int bag_draw(uint32_t& bag, int n_pieces, uint32_t key, uint64_t env) {
 }
 
 // ---- per-set table staged in LDS -------------------------------------------
+// orient[p][L*2+o][0]  packed Orient descriptor (above)
+//                  [1]  threshold shifts into the blocked-thermometer word (valid_mask):
+//                       bits 0-15  four 4-bit shifts for the real thresholds,
+//                       bits 16-31 four 4-bit shifts for the thresholds relaxed by one row
+//                  [2]  rescue rows (valid_mask): for t in {1,2} (board rows R-3+t) at
+//                       5t-5: has | j0<<1 | j1<<3; bit 10 vertical Straight; bit 11 relaxed
+//                       thresholds unconstrained
 struct SetTable {
-  uint32_t orient[kMaxPieces][4];  // [list index][L*2+o]
+  uint32_t orient[kMaxPieces][4][3];
   uint64_t fullmask[kMaxPieces];   // all existing slots (every placement valid)
 };
+
+constexpr uint64_t kLoop0Slots = 0x3333333333333333ull;  // slots with L = 0
+
+// action k -> slot, given the valid mask (game.py:69,83: index into the non-terminal
+// placements in enumeration order)
+TET_HD int slot_of_action(uint64_t mask, int k) {
+  const uint64_t m0 = mask & kLoop0Slots;
+  const int n0 = popc(m0);
+  const bool second = k >= n0;
+  return select_bit(second ? (mask & ~kLoop0Slots) : m0, second ? k - n0 : k);
+}
+// row of slot s in the list of valid (or of all) placements
+TET_HD int row_of_slot(uint64_t mask, int s) {
+  const uint64_t below = (1ull << s) - 1;
+  const uint64_t m0 = mask & kLoop0Slots, m1 = mask & ~kLoop0Slots;
+  return ((s >> 1) & 1) ? popc(m0) + popc(m1 & below) : popc(m0 & below);
+}
 
 template <typename W, int C>
 struct Board {
@@ -213,7 +245,7 @@ TET_HD void board_features(const W (&col)[C], const int (&h)[C], int R, int& row
     f1 += 1 + popc((W)((x ^ ((x << 1) | 1)) & mh));  // state.py:194,206,219-220,242-243
     // hole depth: the top hole of each vertical run counts the filled cells above it
     // (state.py:200,216,239)
-    W T = (W)(ho & (x >> 1));
+    W T = (TET_ABLATE & 16) ? (W)0 : (W)(ho & (x >> 1));
     while (T != 0) {
       int r1 = bitlen(T);  // (index of the top remaining hole) + 1
       f7 += popc((W)(x >> r1));
@@ -240,6 +272,7 @@ TET_HD void board_features(const W (&col)[C], const int (&h)[C], int R, int& row
       f4 += popc(w);
       t = (W)(w & (w >> 1));
     }
+    if (TET_ABLATE & 32) t = 0;
     while (t != 0) {  // runs of k consecutive rows add k(k+1)/2 in total
       f4 += popc(t);
       t = (W)(t & (t >> 1));
@@ -272,116 +305,133 @@ TET_HD void bcts_features(const W (&col)[C], const int (&h)[C], int R, int ancho
 // ---- valid-placement mask ---------------------------------------------------
 // A placement is terminal iff a cell remains in row R after the clear
 // (state.py:33,36,111-117).  The piece spans rows a..a+H-1 with a cell in every
-// one of them and all cleared rows lie inside that span, so
-//      terminal  <=>  a + H - n_cleared > R.
-// Fast form (exact whenever no row >= R-3 can become full, i.e. n_cleared = 0
-// for every placement that pokes above R): valid <=> for all j: h[c+j] <= R-H+b_j.
+// one of them and every cleared row lies inside that span, so
+//      terminal  <=>  e := a + H - R  >  n_cleared.
+// All columns c of one orientation are evaluated at once on small bit-fields:
+//  * slack s_c = R - h_c; footprint column j needs s_{c+j} >= need_j = H - b_j.
+//    X holds per column the 4-bit "blocked thermometer" [s<1, s<2, s<3, s<4];
+//    OR_j (X >> (need_j-1 + 4j)) has bit 4c set iff e >= 1 at column c (I1);
+//    the same with need_j-1 gives e >= 2 (I2).
+//  * e = 1 (I1 & ~I2): the anchor is exactly a = R+1-H, so the piece's row rho sits
+//    in board row R-3+t, t = rho+4-H.  That row becomes full iff all its missing
+//    columns lie inside the piece's (contiguous) run [c+j0, c+j1] of that row, i.e.
+//    c in [hi_t - j1, lo_t - j0] with lo_t/hi_t the lowest/highest missing column.
+//    One full row rescues the placement (n_cleared >= 1 = e).  Only rows below R can
+//    be full (no stack cell sits at row >= R), so t <= 2.
+//  * e >= 2 can only be rescued when H = 4 (vertical Straight): rows R-2 and R-1 must
+//    both miss exactly column c.
 template <typename W, int C>
-TET_HD uint64_t valid_mask_fast(const int (&h)[C], const uint32_t (&d4)[4], int R) {
-  uint32_t lo = 0, hi = 0;
-#pragma unroll
-  for (int lo_ = 0; lo_ < 4; ++lo_) {
-    const int L = lo_ >> 1, oi = lo_ & 1;
-    const Orient o = unpack_orient(d4[lo_]);
-    int thr[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) thr[j] = (j < o.w) ? R - o.H + o.b[j] : 1000;
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-      bool ok = true;
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (c + j < C) ok = ok && (h[c + j] <= thr[j]);
-      const int s = L * 2 * C + 2 * c + oi;
-      if (s < 32) lo |= ok ? (1u << s) : 0u;
-      else hi |= ok ? (1u << (s - 32)) : 0u;
-    }
-  }
-  return ((uint64_t)hi << 32) | lo;
-}
-
-// Exact form: evaluates the clear for placements that poke above row R.
-template <typename W, int C>
-TET_HD uint64_t valid_mask_exact(const W (&col)[C], const int (&h)[C], const uint32_t (&d4)[4], int R) {
-  uint64_t mask = 0;
-#pragma unroll
-  for (int lo_ = 0; lo_ < 4; ++lo_) {
-    const int L = lo_ >> 1, oi = lo_ & 1;
-    const Orient o = unpack_orient(d4[lo_]);
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-      int a = -64;
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (c + j < C) {
-          int v = (j < o.w) ? h[c + j] - o.b[j] : -64;
-          a = v > a ? v : a;
-        }
-      if (a < 0) a = 0;
-      int top = a + o.H;
-      bool ok = top <= R;
-      if (!ok && top <= R + 4) {
-        W F = (W)~(W)0;
-#pragma unroll
-        for (int i = 0; i < C; ++i) {
-          W x = col[i];
-          const int j = i - c;
-          if (j >= 0 && j < 4) {
-            int nj = (j < o.w) ? o.n[j] : 0;
-            x |= (W)(lowmask<W>(nj) << (a + o.b[j]));
-          }
-          F &= x;
-        }
-        ok = (top - popc(F)) <= R;
-      }
-      const int s = L * 2 * C + 2 * c + oi;
-      mask |= ok ? (1ull << s) : 0ull;
-    }
-  }
-  return mask;
-}
-
-// lanes for which the fast form might be wrong: a row r >= R-3 can only become
-// full if at least C-4 columns already reach above it.
-template <typename W, int C>
-TET_HD bool needs_exact_mask(const int (&h)[C], int R) {
-  int tall = 0;
-#pragma unroll
-  for (int c = 0; c < C; ++c) tall += (h[c] >= R - 2) ? 1 : 0;
-  return tall >= C - 4;
-}
-
-template <typename W, int C>
-TET_HD uint64_t valid_mask(const W (&col)[C], const int (&h)[C], const uint32_t (&d4)[4],
+TET_HD uint64_t valid_mask(const W (&col)[C], const int (&h)[C], const uint32_t (&tab)[4][3],
                            uint64_t fullmask, int R) {
-  uint64_t m = valid_mask_fast<W, C>(h, d4, R);
-  if (needs_exact_mask<W, C>(h, R)) m = valid_mask_exact<W, C>(col, h, d4, R);
-  return m & fullmask;
+  static_assert(C <= 10, "missing-cell rows are packed 3 bits per column into 32 bits");
+  uint32_t Xlo = 0, Xhi = 0, Mall = 0;
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    int sl = R - h[c];
+    sl = sl < 4 ? sl : 4;
+    sl = sl > 0 ? sl : 0;
+    const uint32_t th = (0x08CEFu >> (4 * sl)) & 0xFu;  // [s<1, s<2, s<3, s<4]
+    if (c < 8) Xlo |= th << (4 * c);
+    else Xhi |= th << (4 * (c - 8));
+    const uint32_t q = (uint32_t)(col[c] >> (R - 3)) & 7u;  // cells of rows R-3..R-1
+    Mall |= (q ^ 7u) << (3 * c);                            // missing cells
+  }
+  int lo[3], hi[3];
+  uint32_t single[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    const uint32_t m = (Mall >> t) & 0x09249249u;  // bit 3c: column c misses row R-3+t
+    // (a row of a reachable board is never full, so m != 0)
+    lo[t] = m ? (__builtin_ctz(m) * 11) >> 5 : 0;          // /3
+    hi[t] = m ? ((31 - __builtin_clz(m)) * 11) >> 5 : 31;
+    single[t] = (lo[t] == hi[t]) ? (1u << lo[t]) : 0u;
+  }
+  uint32_t mlo = 0, mhi = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const uint32_t shw = tab[k][1], rw = tab[k][2];
+    uint32_t i1lo = 0, i1hi = 0, i2lo = 0, i2hi = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t s1 = (shw >> (4 * j)) & 15u, s2 = (shw >> (16 + 4 * j)) & 15u;
+      const uint64_t X = ((uint64_t)Xhi << 32) | Xlo;
+      i1lo |= (uint32_t)(X >> s1);
+      i1hi |= Xhi >> s1;
+      i2lo |= (uint32_t)(X >> s2);
+      i2hi |= Xhi >> s2;
+    }
+    if ((rw >> 11) & 1u) { i2lo = 0; i2hi = 0; }
+    // rescue by one cleared row (e = 1)
+    uint32_t r1 = 0;
+#pragma unroll
+    for (int t = 1; t < 3; ++t) {
+      const uint32_t f = rw >> (5 * (t - 1));
+      const int j0 = (f >> 1) & 3, j1 = (f >> 3) & 3;
+      int c0 = hi[t] - j1;
+      c0 = c0 > 0 ? c0 : 0;
+      int len = lo[t] - j0 + 1 - c0;
+      len = len > 0 ? len : 0;
+      len = len < 16 ? len : 16;
+      const uint32_t iv = ((1u << len) - 1u) << c0;
+      r1 |= (f & 1u) ? iv : 0u;
+    }
+    uint32_t r2 = 0;
+    if ((rw >> 10) & 1u) {  // vertical Straight: any of its three lower rows / both of R-2, R-1
+      r1 = single[0] | single[1] | single[2];
+      r2 = single[1] & single[2];
+    }
+    // spread bit c -> bit 4c
+    uint32_t a0 = r1 & 0xFFu, b0 = r2 & 0xFFu;
+    a0 = (a0 | (a0 << 12)) & 0x000F000Fu;
+    a0 = (a0 | (a0 << 6)) & 0x03030303u;
+    a0 = (a0 | (a0 << 3)) & 0x11111111u;
+    b0 = (b0 | (b0 << 12)) & 0x000F000Fu;
+    b0 = (b0 | (b0 << 6)) & 0x03030303u;
+    b0 = (b0 | (b0 << 3)) & 0x11111111u;
+    const uint32_t a1 = ((r1 >> 8) & 1u) | (((r1 >> 9) & 1u) << 4);
+    const uint32_t b1 = ((r2 >> 8) & 1u) | (((r2 >> 9) & 1u) << 4);
+    const uint32_t vlo = (~i1lo | (~(i2lo & ~b0) & a0)) & 0x11111111u;
+    const uint32_t vhi = (~i1hi | (~(i2hi & ~b1) & a1)) & 0x11111111u;
+    mlo |= vlo << k;  // slot 4c + 2L + o with k = 2L + o
+    mhi |= vhi << k;
+  }
+  return ((((uint64_t)mhi << 32) | mlo) & fullmask);
 }
 
 // ---- the chosen placement (left column only known at run time) --------------
 // Returns anchor row; stamps the piece into col; pbits[j] = cells added to
-// footprint column j.
+// footprint column j.  Written with arithmetic selects only (no per-lane array
+// indexing): heights travel as packed bytes, the stamp as masked ORs.
 template <typename W, int C>
-TET_HD int stamp_dynamic(W (&col)[C], const int (&h)[C], int c, const Orient& o, W (&pbits)[4]) {
+TET_HD int stamp_dynamic(W (&col)[C], const int (&h)[C], int c, uint32_t d, W (&pbits)[4]) {
+  static_assert(C <= 12, "heights are packed into three 32-bit words");
+  uint32_t P[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+  for (int i = 0; i < C; ++i) P[i >> 2] |= (uint32_t)h[i] << (8 * (i & 3));
+  const int kq = c >> 2;
+  const uint32_t plo = kq == 0 ? P[0] : (kq == 1 ? P[1] : P[2]);
+  const uint32_t phi = kq == 0 ? P[1] : (kq == 1 ? P[2] : P[3]);
+  const uint32_t win = (uint32_t)((((uint64_t)phi << 32) | plo) >> (8 * (c & 3)));  // h[c..c+3]
+  const int w = d & 7;
   int a = 0;
 #pragma unroll
-  for (int i = 0; i < C; ++i) {
-    const int j = i - c;
-    int bj = (j == 0) ? o.b[0] : (j == 1) ? o.b[1] : (j == 2) ? o.b[2] : o.b[3];
-    bool in = (j >= 0) && (j < o.w);
-    int v = in ? h[i] - bj : 0;
-    a = v > a ? v : a;
+  for (int j = 0; j < 4; ++j) {
+    const int bj = (d >> (6 + 5 * j)) & 3;
+    const int v = (int)((win >> (8 * j)) & 255u) - bj;
+    a = (j < w && v > a) ? v : a;
   }
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    int nj = (j < o.w) ? o.n[j] : 0;
-    pbits[j] = (W)(lowmask<W>(nj) << (a + o.b[j]));
+    const int bj = (d >> (6 + 5 * j)) & 3;
+    const int nj = (j < w) ? (int)((d >> (8 + 5 * j)) & 7) : 0;
+    pbits[j] = (W)(lowmask<W>(nj) << (a + bj));
   }
 #pragma unroll
   for (int i = 0; i < C; ++i) {
-    const int j = i - c;
-    W add = (j == 0) ? pbits[0] : (j == 1) ? pbits[1] : (j == 2) ? pbits[2] : (j == 3) ? pbits[3] : (W)0;
+    W add = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (i - j >= 0) add |= (W)(pbits[j] & (W)(0 - (W)(c == i - j)));
     col[i] |= add;
   }
   return a;
@@ -429,32 +479,32 @@ TET_HD void env_step(W (&col)[C], uint64_t& meta, int action, const SetTable& ta
     out.piece = piece;
     return;
   }
-  // decode action -> (loop, column, orientation): game.py:69,83
-  const int s = select_bit(mask, action);
-  const int L = (s >= 2 * C) ? 1 : 0;
-  const int q = s - L * 2 * C;
-  const int c = q >> 1;
-  const int oi = q & 1;
-  const Orient o = unpack_orient(tab.orient[piece][L * 2 + oi]);
+  // decode action -> slot 4c + 2L + o: game.py:69,83
+  const int s = slot_of_action(mask, action);
+  const int c = s >> 2;
+  const uint32_t od = tab.orient[piece][s & 3][0];
+  const int oH = (od >> 3) & 7;
 
   int h[C];
   heights_of<W, C>(col, h);
   W pbits[4];
-  const int a = stamp_dynamic<W, C>(col, h, c, o, pbits);  // tetromino.py get_after_states
+  const int a = stamp_dynamic<W, C>(col, h, c, od, pbits);  // tetromino.py get_after_states
   int eroded = 0;
-  const int k = clear_lines<W, C>(col, pbits, &eroded);   // state.py:33
+  const int k = (TET_ABLATE & 8) ? 0 : clear_lines<W, C>(col, pbits, &eroded);   // state.py:33
   heights_of<W, C>(col, h);
-  bcts_features<W, C>(col, h, R, a, o.H, eroded, k, out.obs);  // game.py:91
+  if (TET_ABLATE & 1) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) out.obs[i] = (float)h[i];
+  } else
+  bcts_features<W, C>(col, h, R, a, oH, eroded, k, out.obs);  // game.py:91
   if (cfg.has_direct_by) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) out.obs[i] *= cfg.direct_by[i];
   }
   // game.py:87 next piece, :88 is_game_over for THAT piece
   int np = draw >= 0 ? draw : bag_draw(bag, cfg.n_pieces, cfg.key_step, env);
-  uint32_t d4[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) d4[i] = tab.orient[np][i];
-  uint64_t nmask = valid_mask<W, C>(col, h, d4, tab.fullmask[np], R);
+  uint64_t nmask = (TET_ABLATE & 2) ? (tab.fullmask[np] ^ (uint64_t)h[0])
+                                    : valid_mask<W, C>(col, h, tab.orient[np], tab.fullmask[np], R);
   int nnv = popc(nmask);
   int done = nnv == 0;
   out.reward = k - 1 + (done ? -100 : 0);  // game.py:86,89-90 (rewards :34-35)

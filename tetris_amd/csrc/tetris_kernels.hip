@@ -188,10 +188,7 @@ __global__ __launch_bounds__(kBlock) void refresh_kernel(const RefreshParams p) 
   tet::heights_of<W, C>(col, h);
   const uint64_t meta = p.meta[i];
   const int piece = tet::meta_piece(meta);
-  uint32_t d4[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) d4[k] = tab.orient[piece][k];
-  const uint64_t mask = tet::valid_mask<W, C>(col, h, d4, tab.fullmask[piece], p.R);
+  const uint64_t mask = tet::valid_mask<W, C>(col, h, tab.orient[piece], tab.fullmask[piece], p.R);
   p.meta[i] = tet::meta_pack(mask, piece, tet::meta_bag(meta));
   if (p.n_valid_out) p.n_valid_out[i] = (uint8_t)tet::popc(mask);
 }
@@ -234,15 +231,13 @@ __global__ __launch_bounds__(kBlock) void afterstates_kernel(const AfterParams p
   const int nv = tet::popc(valid), na = tet::popc(full);
 #pragma unroll 1
   for (int lo = 0; lo < 4; ++lo) {
-    const tet::Orient o = tet::unpack_orient(tab.orient[piece][lo]);
+    const tet::Orient o = tet::unpack_orient(tab.orient[piece][lo][0]);
     if (!o.exists) continue;
 #pragma unroll
     for (int c = 0; c < C; ++c) {
-      // slot order (loop, column, orientation) is the reference's enumeration order,
-      // so the row of a placement is the number of set bits below its slot
-      const int s = (lo >> 1) * 2 * C + 2 * c + (lo & 1);
+      // the row of a placement follows the reference's enumeration order (tet::row_of_slot)
+      const int s = 4 * c + lo;
       if (!((full >> s) & 1)) continue;
-      const uint64_t below = (1ull << s) - 1;
       W nb[C];
       W pbits[4];
       int nh[C];
@@ -257,12 +252,12 @@ __global__ __launch_bounds__(kBlock) void afterstates_kernel(const AfterParams p
         for (int q = 0; q < 8; ++q) f[q] *= p.direct_by[q];
       }
       if (out_all) {
-        float4* d = reinterpret_cast<float4*>(out_all + tet::popc(full & below) * 8);
+        float4* d = reinterpret_cast<float4*>(out_all + tet::row_of_slot(full, s) * 8);
         d[0] = make_float4(f[0], f[1], f[2], f[3]);
         d[1] = make_float4(f[4], f[5], f[6], f[7]);
       }
       if ((valid >> s) & 1) {  // game.py:69
-        float4* d = reinterpret_cast<float4*>(out_valid + tet::popc(valid & below) * 8);
+        float4* d = reinterpret_cast<float4*>(out_valid + tet::row_of_slot(valid, s) * 8);
         d[0] = make_float4(f[0], f[1], f[2], f[3]);
         d[1] = make_float4(f[4], f[5], f[6], f[7]);
       }

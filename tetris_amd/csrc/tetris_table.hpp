@@ -55,6 +55,51 @@ inline int n_placements(int pid, int C) {
   return total;
 }
 
+// thresholds: footprint column j needs slack R - h >= need_j = H - b_j; the shift
+// need_j - 1 + 4j picks that level of column c+j's thermometer nibble (valid_mask)
+inline void pack_mask_words(const CatOrient& o, uint32_t* shifts, uint32_t* rescue) {
+  int H = 0;
+  for (int j = 0; j < o.w; ++j)
+    if (o.b[j] + o.n[j] > H) H = o.b[j] + o.n[j];
+  uint32_t sh1[4], sh2[4];
+  int first2 = -1;
+  for (int j = 0; j < o.w; ++j) {
+    const int need = H - o.b[j];
+    sh1[j] = (uint32_t)(need - 1 + 4 * j);
+    if (need - 1 >= 1) {
+      sh2[j] = (uint32_t)(need - 2 + 4 * j);
+      if (first2 < 0) first2 = j;
+    } else {
+      sh2[j] = 0xFFu;  // unconstrained once relaxed
+    }
+  }
+  for (int j = o.w; j < 4; ++j) {  // absent columns repeat column 0's term (OR is idempotent)
+    sh1[j] = sh1[0];
+    sh2[j] = 0xFFu;
+  }
+  uint32_t sw = 0, rw = 0;
+  for (int j = 0; j < 4; ++j) {
+    if (sh2[j] == 0xFFu) sh2[j] = first2 >= 0 ? sh2[first2] : 0u;
+    sw |= sh1[j] << (4 * j);
+    sw |= sh2[j] << (16 + 4 * j);
+  }
+  if (first2 < 0) rw |= 1u << 11;
+  if (o.w == 1 && H == 4) rw |= 1u << 10;
+  for (int t = 1; t < 3; ++t) {  // board row R-3+t holds piece row rho when the anchor is R+1-H
+    const int rho = t - 4 + H;
+    if (rho < 0 || rho > H - 2) continue;
+    int j0 = -1, j1 = -1;
+    for (int j = 0; j < o.w; ++j)
+      if (o.b[j] <= rho && rho < o.b[j] + o.n[j]) {
+        if (j0 < 0) j0 = j;
+        j1 = j;
+      }
+    rw |= (1u | ((uint32_t)j0 << 1) | ((uint32_t)j1 << 3)) << (5 * (t - 1));
+  }
+  *shifts = sw;
+  *rescue = rw;
+}
+
 inline void build_table(const TetrisDesc* d, SetTable* t) {
   memset(t, 0, sizeof(*t));
   const int C = d->num_columns;
@@ -63,13 +108,14 @@ inline void build_table(const TetrisDesc* d, SetTable* t) {
     uint64_t full = 0;
     for (int l = 0; l < 2; ++l)
       for (int oi = 0; oi < p.n_orient[l]; ++oi) {
-        t->orient[i][l * 2 + oi] = pack_orient(p.o[l][oi]);
-        for (int c = 0; c + p.o[l][oi].w <= C; ++c) full |= 1ull << (l * 2 * C + 2 * c + oi);
+        uint32_t* e = t->orient[i][l * 2 + oi];
+        e[0] = pack_orient(p.o[l][oi]);
+        pack_mask_words(p.o[l][oi], &e[1], &e[2]);
+        for (int c = 0; c + p.o[l][oi].w <= C; ++c) full |= 1ull << (4 * c + 2 * l + oi);
       }
     t->fullmask[i] = full;
   }
 }
-
 
 // num_columns values the kernels are instantiated for (one place for the
 // library, the dispatch switch and the CPU test harness)

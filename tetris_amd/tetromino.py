@@ -56,8 +56,7 @@ def n_placements(name, num_columns):
 
 def placement_of_slot(name, num_columns, slot):
     """Static slot index (bit of the valid mask) -> (loop, column, orientation index)."""
-    loop, q = divmod(slot, 2 * num_columns)
-    return loop, q >> 1, q & 1
+    return (slot >> 1) & 1, slot >> 2, slot & 1
 
 
 class Tetromino:

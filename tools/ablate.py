@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Timing-only ablation of the step kernel: builds libtetris_hip variants with
+-DTET_ABLATE=<mask> (parts of the step removed -> wrong results, same memory
+traffic) and times the step kernel of each with HIP events, interleaved A/B in
+one process.  bit0 features, bit1 next-piece mask, bit2 exact-mask path, bit3 clear."""
+import ctypes
+import os
+import subprocess
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from tetris_amd import _lib, build  # noqa: E402
+from tetris_amd import VecTetris  # noqa: E402
+
+masks = [int(x) for x in (sys.argv[1:] or ["0", "1", "2", "4", "8", "3", "15"])]
+rows = int(os.environ.get("ABL_ROWS", "20"))
+pieces = os.environ.get("ABL_PIECES", "default")
+src = os.path.join(ROOT, "tetris_amd", "csrc", "tetris_kernels.hip")
+libs = {}
+for m in masks:
+    out = "/tmp/libtetris_abl_%d.so" % m
+    subprocess.check_call([build._hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
+                           "-DTET_ABLATE=%d" % m, src, "-o", out])
+    libs[m] = _lib._Binding(ctypes.CDLL(out))
+
+B = 1 << 20
+base = VecTetris(10, rows, B, device="cuda", pieces=pieces, auto_reset=True, seed=0)
+for t in range(200):
+    base.step(base.random_actions())
+snap = base.state_dict()
+res = {m: [] for m in masks}
+for rep in range(5):
+    for m in masks:
+        base.load_state_dict(snap)
+        base._lib = libs[m]
+        acts = base.random_actions().clone()
+        evs = []
+        for t in range(20):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            base.step(acts)
+            e.record()
+            evs.append((s, e))
+        torch.cuda.synchronize()
+        ts = sorted(s.elapsed_time(e) for s, e in evs)
+        res[m].append(sum(ts[2:-2]) / len(ts[2:-2]))
+for m in masks:
+    print("ablate=%2d  step kernel %.1f us  (runs: %s)" % (m, 1e3 * min(res[m]), " ".join("%.1f" % (1e3 * x) for x in res[m])))
