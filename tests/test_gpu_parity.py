@@ -48,3 +48,14 @@ def test_tall_board_cfg5_properties():
 def test_mask_rescue_stress(orc):
     pc.mask_rescue_stress(DEV, orc, n_boards=1500)
     pc.mask_rescue_stress(DEV, orc, n_boards=500, R=40, seed=1)
+
+
+def test_facade_golden_trajectories(golden_dir):
+    """game.Tetris drop-in (batch of one) replaying recorded reference runs on the GPU."""
+    import facade_cases as fc
+    fc.golden_trajectory(DEV, golden_dir, "default", 20, 0)
+    fc.golden_trajectory(DEV, golden_dir, "standard7", 40, 1, steps=120)
+    fc.dtypes_and_directions(DEV, golden_dir)
+    fc.reset_features(DEV, golden_dir)
+    fc.best_policy(DEV, golden_dir)
+    fc.rollouts_and_misc(DEV)

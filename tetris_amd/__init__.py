@@ -6,5 +6,7 @@ gfx950 behind the C-ABI of include/tetris_hip.h.
 """
 from .tetromino import CATALOGUE, PIECE_SETS, Tetromino, TetrominoSampler  # noqa: F401
 from .vec_env import VecTetris  # noqa: F401
+from .game import Tetris  # noqa: F401
+from .state import State  # noqa: F401
 
-__all__ = ["VecTetris", "CATALOGUE", "PIECE_SETS", "Tetromino", "TetrominoSampler"]
+__all__ = ["VecTetris", "Tetris", "State", "CATALOGUE", "PIECE_SETS", "Tetromino", "TetrominoSampler"]

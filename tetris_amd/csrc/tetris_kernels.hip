@@ -21,6 +21,11 @@ using tet::check_desc;
 
 constexpr int kBlock = 256;
 
+// minimum waves per SIMD the step kernel is compiled for (bounds its VGPR budget)
+#ifndef TET_STEP_WAVES
+#define TET_STEP_WAVES 1
+#endif
+
 // ---- kernels ------------------------------------------------------------------
 
 __device__ __forceinline__ void stage_table(SetTable& lds, const SetTable& arg) {
@@ -63,7 +68,7 @@ struct StepParams {
 };
 
 template <typename W, int C>
-__global__ __launch_bounds__(kBlock) void step_kernel(const StepParams p) {
+__global__ __launch_bounds__(kBlock, TET_STEP_WAVES) void step_kernel(const StepParams p) {
   __shared__ SetTable tab;
   stage_table(tab, p.tab);
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;

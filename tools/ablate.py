@@ -16,6 +16,8 @@ from tetris_amd import _lib, build  # noqa: E402
 from tetris_amd import VecTetris  # noqa: E402
 
 masks = [int(x) for x in (sys.argv[1:] or ["0", "1", "2", "4", "8", "3", "15"])]
+extra = os.environ.get("ABL_FLAGS", "").split()
+# a mask >= 1000 means: TET_STEP_WAVES = mask // 1000, TET_ABLATE = mask % 1000
 rows = int(os.environ.get("ABL_ROWS", "20"))
 pieces = os.environ.get("ABL_PIECES", "default")
 src = os.path.join(ROOT, "tetris_amd", "csrc", "tetris_kernels.hip")
@@ -23,7 +25,8 @@ libs = {}
 for m in masks:
     out = "/tmp/libtetris_abl_%d.so" % m
     subprocess.check_call([build._hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
-                           "-DTET_ABLATE=%d" % m, src, "-o", out])
+                           "-DTET_ABLATE=%d" % (m % 1000), "-DTET_STEP_WAVES=%d" % max(1, m // 1000)] + extra +
+                          [src, "-o", out])
     libs[m] = _lib._Binding(ctypes.CDLL(out))
 
 B = 1 << 20
