@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""BASELINE config 1: one 10x20 board, random-action rollout through the facade.
+
+The role of the reference's example_play.py (which crashes upstream because it iterates the
+(features, None) tuple of get_after_states): unpack the tuple, pick a random valid
+action, step, reset on done."""
+import os
+import random
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tetris_amd import Tetris  # noqa: E402
+
+np.random.seed(0)
+random.seed(0)
+env = Tetris(10, 20)
+total, episodes = 0, 0
+for t in range(200):
+    features, _ = env.get_after_states()
+    action = random.randrange(len(features))
+    obs, reward, done, lines = env.step(action)
+    total += lines
+    if done:
+        episodes += 1
+        env.reset()
+env.render()
+print("200 steps, %d episodes finished, %d lines cleared" % (episodes, total))
