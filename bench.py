@@ -3,10 +3,10 @@
 
   python bench.py --gpus N --steps K --warmup W
 
-One "step" = one pass of the hot path over the whole batch: the random-policy
-kernel (uniform valid action per env) + the fused step kernel (decode, land,
-lock, clear, done, reward, BCTS observation, in-kernel auto-reset), every output
-tensor written.  Workload at N = 1: BASELINE config 3 -- 1,048,576 envs, 10x20
+One "step" = one pass of the hot path over the whole batch: ONE launch of the
+fused step kernel (uniform random valid action per env drawn in-kernel and written
+out, decode, land, lock, clear, done, reward, BCTS observation, in-kernel
+auto-reset), every output tensor written.  Workload at N = 1: BASELINE config 3 -- 1,048,576 envs, 10x20
 board, default piece set; N > 1 is config 4 (weak scaling, 1,048,576 envs per
 GPU, contiguous env shards, no data-path collective; RCCL only gathers the
 done counters / done bitmask).
@@ -115,8 +115,7 @@ def main():
         torch.cuda.synchronize(dev)
 
     def one_step(t):
-        a = env.random_actions()
-        env.step(a)
+        env.step()  # action = None: uniform random valid action drawn inside the step kernel
         if world > 1 and (t + 1) % args.gather_every == 0:
             gather.gather_counters(env.totals())
 
@@ -140,9 +139,8 @@ def main():
     n_prof = 50
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_prof)]
     for s, e in evs:
-        a = env.random_actions()
         s.record()
-        env.step(a)
+        env.step()
         e.record()
     torch.cuda.synchronize(dev)
     k_ms = sorted(s.elapsed_time(e) for s, e in evs)

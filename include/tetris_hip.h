@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define TETRIS_HIP_ABI_VERSION 1
+#define TETRIS_HIP_ABI_VERSION 2
 
 #define TETRIS_MAX_PIECES 12
 #define TETRIS_MAX_COLUMNS 10
@@ -59,7 +59,7 @@ enum {
   TETRIS_E_COLUMNS = -3,     /* num_columns not built into this library */
   TETRIS_E_ROWS = -4,        /* num_rows outside [4, 59] */
   TETRIS_E_PIECES = -5,      /* bad piece list */
-  TETRIS_E_BATCH = -6,       /* B <= 0 */
+  TETRIS_E_BATCH = -6,       /* B <= 0 or B * num_columns * word_bytes >= 2^31 */
   TETRIS_E_STREAM = -7       /* replay stream given without cursor / length */
 };
 
@@ -116,7 +116,10 @@ int tetris_hip_reset(const TetrisDesc* desc, void* cols, uint64_t* meta, const u
  * next piece (game.py:94-100), the BCTS observation (state.py:97-107,175-280)
  * and, when auto_reset != 0, reset() of finished envs (game.py:53-63).
  *
- *  action       : int32[B] index into the non-terminal placements
+ *  action       : int32[B] index into the non-terminal placements, or NULL: every env
+ *                 plays a uniform random valid action (the same one
+ *                 tetris_hip_policy_random would return for this seed / step_idx)
+ *  action_out   : int32[B] or NULL: the action each env played
  *  obs          : float32[B][8]   observation of the chosen afterstate
  *  reward       : int32[B]        lines - 1 (- 100 when done)   game.py:86-90
  *  done         : uint8[B]
@@ -130,7 +133,7 @@ int tetris_hip_reset(const TetrisDesc* desc, void* cols, uint64_t* meta, const u
  * status[TETRIS_STATUS_INVALID].
  */
 int tetris_hip_step(const TetrisDesc* desc, void* cols, uint64_t* meta, const int32_t* action,
-                    const uint8_t* stream, int32_t* cursor, int64_t stream_len, float* obs,
+                    int32_t* action_out, const uint8_t* stream, int32_t* cursor, int64_t stream_len, float* obs,
                     int32_t* reward, uint8_t* done, uint8_t* lines, uint8_t* n_valid_next,
                     uint8_t* piece_next, uint32_t* status, int32_t auto_reset, uint64_t seed,
                     uint64_t step_idx, int64_t env_offset, int64_t B, void* hip_stream);

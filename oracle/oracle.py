@@ -127,6 +127,7 @@ class OracleVecEnv:
         self.done = np.zeros(batch_size, np.uint8)
         self.lines = np.zeros(batch_size, np.uint8)
         self.invalid = np.zeros(batch_size, np.uint8)
+        self.action = np.zeros(batch_size, np.int32)
         self.reset(init_bag=True)
 
     def reset(self, init_bag=False):
@@ -136,11 +137,14 @@ class OracleVecEnv:
             _p(self.cursor), ctypes.c_int64(slen), _p(self.n_valid), int(init_bag), ctypes.c_uint64(self.seed),
             ctypes.c_uint64(self.step_idx), ctypes.c_int64(self.env_offset), ctypes.c_int64(self.B))
 
-    def step(self, action):
-        action = np.ascontiguousarray(action, dtype=np.int32)
+    def step(self, action=None):
+        """action None = the build's uniform random policy (recorded in self.action)."""
+        if action is not None:
+            action = np.ascontiguousarray(action, dtype=np.int32)
         slen = 0 if self.stream is None else self.stream.shape[0]
         n_bad = lib().orc_step_batch(
-            ctypes.byref(self.desc), _p(self.cells), _p(self.piece), _p(self.bag), _p(action), _p(self.stream),
+            ctypes.byref(self.desc), _p(self.cells), _p(self.piece), _p(self.bag), _p(action), _p(self.action),
+            _p(self.stream),
             _p(self.cursor), ctypes.c_int64(slen), _p(self.obs), _p(self.reward), _p(self.done), _p(self.lines),
             _p(self.n_valid), _p(self.invalid), self.auto_reset, ctypes.c_uint64(self.seed),
             ctypes.c_uint64(self.step_idx), ctypes.c_int64(self.env_offset), ctypes.c_int64(self.B),

@@ -368,19 +368,19 @@ uint32_t orc_hash32(uint64_t seed, uint64_t env, uint64_t counter) {
   k = mix32(k ^ (uint32_t)(seed >> 32));
   k = mix32(k ^ (uint32_t)counter);
   k = mix32(k ^ (uint32_t)(counter >> 32));
-  uint32_t h = mix32(k ^ (uint32_t)env);
-  h = mix32(h ^ (uint32_t)(env >> 32) ^ 0x85EBCA6BU);
+  uint32_t h = (k ^ (uint32_t)env) * 0x9E3779B1U; /* global env index mod 2^32 */
+  h ^= h >> 16;
+  h *= 0x85EBCA6BU;
+  h ^= h >> 13;
   return h;
 }
 
 /* Bag without replacement: same distribution as popping a fresh
- * np.random.permutation front to back (tetromino.py:17-22). */
-int orc_bag_draw(uint16_t* bag, int n_pieces, uint64_t seed, uint64_t env, uint64_t step_idx,
-                 int phase) {
+ * np.random.permutation front to back (tetromino.py:17-22).  r16 = 16 random bits. */
+int orc_bag_draw(uint16_t* bag, int n_pieces, uint32_t r16) {
   if (*bag == 0) *bag = (uint16_t)((1u << n_pieces) - 1u);
   int m = __builtin_popcount(*bag);
-  uint32_t r = orc_hash32(seed, env, step_idx * 4u + (uint64_t)phase);
-  int k = (int)(((uint64_t)r * (uint64_t)m) >> 32);
+  int k = (int)((r16 * (uint32_t)m) >> 16);
   int p = -1;
   for (int i = 0; i < n_pieces; ++i) {
     if ((*bag >> i) & 1) {
@@ -395,6 +395,8 @@ int orc_bag_draw(uint16_t* bag, int n_pieces, uint64_t seed, uint64_t env, uint6
   return p;
 }
 
+/* phase 0: draw inside step (high 16 bits of the step hash); phase 1: draw of the in-step
+ * reset (low 16 bits of the same hash); phase 2: explicit reset (its own counter) */
 static int next_piece(const OrcDesc* d, uint16_t* bag, const uint8_t* stream, int32_t* cursor,
                       int64_t stream_len, int64_t i, int64_t B, uint64_t seed, uint64_t env,
                       uint64_t step_idx, int phase) {
@@ -404,7 +406,9 @@ static int next_piece(const OrcDesc* d, uint16_t* bag, const uint8_t* stream, in
     cursor[i] += 1;
     return stream[row * B + i];
   }
-  return orc_bag_draw(&bag[i], d->n_pieces, seed, env, step_idx, phase);
+  if (phase == 2) return orc_bag_draw(&bag[i], d->n_pieces, orc_hash32(seed, env, step_idx * 4u + 2u) >> 16);
+  uint32_t h = orc_hash32(seed, env, step_idx * 4u);
+  return orc_bag_draw(&bag[i], d->n_pieces, phase == 0 ? h >> 16 : h & 0xFFFFu);
 }
 
 /* ----- batched env -------------------------------------------------------- */
@@ -434,7 +438,7 @@ void orc_reset_batch(const OrcDesc* d, int8_t* cells, int32_t* piece, uint16_t* 
 }
 
 int64_t orc_step_batch(const OrcDesc* d, int8_t* cells, int32_t* piece, uint16_t* bag,
-                       const int32_t* action, const uint8_t* stream, int32_t* cursor,
+                       const int32_t* action, int32_t* action_out, const uint8_t* stream, int32_t* cursor,
                        int64_t stream_len, float* obs, int32_t* reward, uint8_t* done,
                        uint8_t* lines, uint8_t* n_valid_next, uint8_t* invalid, int auto_reset,
                        uint64_t seed, uint64_t step_idx, int64_t env_offset, int64_t B,
@@ -453,15 +457,27 @@ int64_t orc_step_batch(const OrcDesc* d, int8_t* cells, int32_t* piece, uint16_t
     state_from_flat(d, my, &cur);
     /* game.py:68-69: enumerate, keep the non-terminal ones in order */
     int n = orc_enumerate(d, &cur, d->piece_ids[piece[i]], after);
+    int n_cur = 0;
+    for (int k = 0; k < n; ++k) n_cur += !after[k].terminal;
+    /* action == NULL: the build's uniform random policy (16 hash bits scaled to n_valid) */
+    int act = action ? action[i]
+                     : (int)(((orc_hash32(seed, (uint64_t)(env_offset + i), step_idx * 4u + 3u) >> 16) *
+                              (uint32_t)n_cur) >> 16);
+    if (action_out) action_out[i] = act;
     int chosen = -1, seen = 0;
     for (int k = 0; k < n; ++k) {
       if (after[k].terminal) continue;
-      if (seen == action[i]) chosen = k;
+      if (seen == act) chosen = k;
       ++seen;
     }
-    if (action[i] < 0 || chosen < 0) { /* game.py:83 would raise IndexError */
+    if (act < 0 || chosen < 0) { /* game.py:83 would raise IndexError: env untouched, outputs zeroed */
       invalid[i] = 1;
       ++n_invalid;
+      for (int q = 0; q < 8; ++q) obs[i * 8 + q] = 0.0f;
+      reward[i] = 0;
+      done[i] = (uint8_t)(n_cur == 0);
+      lines[i] = 0;
+      n_valid_next[i] = (uint8_t)n_cur;
       continue;
     }
     invalid[i] = 0;

@@ -87,13 +87,14 @@ void orc_board_features_flat(const OrcDesc* d, const int8_t* cells, float f[8]);
  *  bag         : [B] bitmask of list indices still in the bag (device-bag mode)
  *  stream/cursor: replay mode when stream != NULL: stream is [stream_len][B]
  *                 (u8 list indices), cursor[B] = next unread row per env.
- *  action      : [B] index into the NON-TERMINAL placements (game.py:69,83)
+ *  action      : [B] index into the NON-TERMINAL placements (game.py:69,83); NULL = the
+ *                build's uniform random policy; action_out (optional) receives it
  *  invalid     : [B] set to 1 where action is out of range (env untouched)
  * Mirrors game.py:82-92 (step), 94-100 (is_game_over), 53-63 (reset when
  * auto_reset and done).  Returns the number of invalid actions.
  * ------------------------------------------------------------------------- */
 int64_t orc_step_batch(const OrcDesc* d, int8_t* cells, int32_t* piece,
-                       uint16_t* bag, const int32_t* action,
+                       uint16_t* bag, const int32_t* action, int32_t* action_out,
                        const uint8_t* stream, int32_t* cursor, int64_t stream_len,
                        float* obs, int32_t* reward, uint8_t* done, uint8_t* lines,
                        uint8_t* n_valid_next, uint8_t* invalid,
@@ -119,8 +120,7 @@ void orc_afterstates_batch(const OrcDesc* d, const int8_t* cells,
 /* counter-based bag draw shared with the HIP kernel (build design, not from
  * the reference; same distribution as tetromino.py:12-22). */
 uint32_t orc_hash32(uint64_t seed, uint64_t env, uint64_t counter);
-int orc_bag_draw(uint16_t* bag, int n_pieces, uint64_t seed, uint64_t env,
-                 uint64_t step_idx, int phase);
+int orc_bag_draw(uint16_t* bag, int n_pieces, uint32_t r16);
 
 /* NumPy legacy RandomState (MT19937) restatement, tetromino.py:15,19 call
  * np.random.permutation(n) on the global stream.  state = 625 uint32. */

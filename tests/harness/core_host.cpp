@@ -18,7 +18,8 @@
 namespace {
 
 template <typename W, int C>
-void step_impl(const TetrisDesc* desc, void* cols_, uint64_t* meta, const int32_t* action, const uint8_t* stream,
+void step_impl(const TetrisDesc* desc, void* cols_, uint64_t* meta, const int32_t* action, int32_t* action_out,
+               const uint8_t* stream,
                int32_t* cursor, int64_t stream_len, float* obs, int32_t* reward, uint8_t* done, uint8_t* lines,
                uint8_t* n_valid, uint8_t* piece_next, uint32_t* status, int auto_reset, uint64_t seed,
                uint64_t step_idx, int64_t env_offset, int64_t B) {
@@ -29,7 +30,7 @@ void step_impl(const TetrisDesc* desc, void* cols_, uint64_t* meta, const int32_
   cfg.n_pieces = desc->n_pieces;
   cfg.auto_reset = auto_reset;
   cfg.key_step = tet::hash_key(seed, step_idx * 4u + 0u);
-  cfg.key_reset = tet::hash_key(seed, step_idx * 4u + 1u);
+  cfg.key_policy = tet::hash_key(seed, step_idx * 4u + 3u);
   cfg.has_direct_by = desc->has_direct_by;
   for (int i = 0; i < 8; ++i) cfg.direct_by[i] = desc->direct_by[i];
   W* cols = static_cast<W*>(cols_);
@@ -46,7 +47,9 @@ void step_impl(const TetrisDesc* desc, void* cols_, uint64_t* meta, const int32_
       draw_reset = stream[r1 * B + i];
     }
     tet::StepOut out;
-    tet::env_step<W, C>(col, m, action[i], tab, cfg, (uint64_t)(env_offset + i), draw, draw_reset, out);
+    tet::env_step<W, C>(col, m, action ? action[i] : -1, action == nullptr, tab, cfg, (uint32_t)(env_offset + i),
+                        draw, draw_reset, out);
+    if (action_out) action_out[i] = out.action;
     if (!out.invalid) {
       for (int c = 0; c < C; ++c) cols[(int64_t)c * B + i] = col[c];
       meta[i] = m;
@@ -89,7 +92,7 @@ void reset_impl(const TetrisDesc* desc, void* cols_, uint64_t* meta, const uint8
       piece = stream[r0 * B + i];
       cursor[i] = cur + 1;
     } else {
-      piece = tet::bag_draw(bag, desc->n_pieces, key, (uint64_t)(env_offset + i));
+      piece = tet::bag_draw(bag, desc->n_pieces, tet::hash_env(key, (uint32_t)(env_offset + i)) >> 16);
     }
     const uint64_t mask = tab.fullmask[piece];
     meta[i] = tet::meta_pack(mask, piece, bag);
@@ -194,13 +197,13 @@ int tetris_host_desc_init(TetrisDesc* desc, int32_t num_columns, int32_t num_row
 }
 
 int tetris_host_step(const TetrisDesc* desc, void* cols, uint64_t* meta, const int32_t* action,
-                     const uint8_t* stream, int32_t* cursor, int64_t stream_len, float* obs, int32_t* reward,
+                     int32_t* action_out, const uint8_t* stream, int32_t* cursor, int64_t stream_len, float* obs, int32_t* reward,
                      uint8_t* done, uint8_t* lines, uint8_t* n_valid_next, uint8_t* piece_next, uint32_t* status,
                      int32_t auto_reset, uint64_t seed, uint64_t step_idx, int64_t env_offset, int64_t B,
                      void* unused) {
   (void)unused;
   return dispatch(desc, [&](auto w, auto c) {
-    step_impl<decltype(w), decltype(c)::value>(desc, cols, meta, action, stream, cursor, stream_len, obs, reward, done,
+    step_impl<decltype(w), decltype(c)::value>(desc, cols, meta, action, action_out, stream, cursor, stream_len, obs, reward, done,
                                                lines, n_valid_next, piece_next, status, auto_reset, seed, step_idx,
                                                env_offset, B);
   });
@@ -238,8 +241,7 @@ int tetris_host_policy_random(const uint8_t* n_valid, int32_t* action, uint64_t 
   (void)unused;
   const uint32_t key = tet::hash_key(seed, step_idx * 4u + 3u);
   for (int64_t i = 0; i < B; ++i) {
-    const uint32_t r = tet::hash_env(key, (uint64_t)(env_offset + i));
-    action[i] = (int32_t)(((uint64_t)r * (uint64_t)n_valid[i]) >> 32);
+    action[i] = tet::policy_random(key, (uint32_t)(env_offset + i), n_valid[i]);
   }
   return 0;
 }

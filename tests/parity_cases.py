@@ -28,9 +28,14 @@ def lockstep(device, orc, C, R, B, pieces, steps, seed, auto_reset=True, env_off
             np.testing.assert_array_equal(na.cpu().numpy(), rna)
             np.testing.assert_array_equal(f.cpu().numpy(), rf)
             np.testing.assert_array_equal(fa.cpu().numpy(), rfa)
-        a = env.random_actions().clone()
-        obs, rew, done, lines = env.step(a)
-        o_obs, o_rew, o_done, o_lines, n_bad = ref.step(a.cpu().numpy())
+        if t % 2 == 0:  # explicit actions (from the policy kernel) ...
+            a = env.random_actions().clone()
+            obs, rew, done, lines = env.step(a)
+            o_obs, o_rew, o_done, o_lines, n_bad = ref.step(a.cpu().numpy())
+        else:           # ... and the policy fused into the step kernel
+            obs, rew, done, lines = env.step()
+            o_obs, o_rew, o_done, o_lines, n_bad = ref.step()
+            np.testing.assert_array_equal(env.action.cpu().numpy(), ref.action)
         assert n_bad == 0
         np.testing.assert_array_equal(obs.cpu().numpy(), o_obs, err_msg="obs t=%d" % t)  # bit-exact float32
         np.testing.assert_array_equal(rew.cpu().numpy(), o_rew)
@@ -169,10 +174,9 @@ def full_size_properties(device, B=1 << 20, steps=60, R=20):
     cells_before = None
     total_lines = 0
     for t in range(steps):
-        a = env.random_actions()
         before = env.boards().sum(dim=(1, 2), dtype=torch.int32) if t % 20 == 0 else None
         piece_cells = 3  # both default pieces have 3 cells
-        obs, rew, done, lines = env.step(a)
+        obs, rew, done, lines = env.step()
         if before is not None:
             after = env.boards().sum(dim=(1, 2), dtype=torch.int32)
             keep = ~done

@@ -96,19 +96,21 @@ inline uint32_t hash_key(uint64_t seed, uint64_t counter) {
   k = mix32(k ^ (uint32_t)(counter >> 32));
   return k;
 }
-TET_HD uint32_t hash_env(uint32_t key, uint64_t env) {
-  uint32_t h = mix32(key ^ (uint32_t)env);
-  return mix32(h ^ (uint32_t)(env >> 32) ^ 0x85EBCA6BU);
+// per-env part (two multiplies); env = global env index mod 2^32
+TET_HD uint32_t hash_env(uint32_t key, uint32_t env) {
+  uint32_t h = (key ^ env) * 0x9E3779B1U;
+  h ^= h >> 16;
+  h *= 0x85EBCA6BU;
+  h ^= h >> 13;
+  return h;
 }
+// uniform integer in [0, n) from 16 random bits (n <= 64)
+TET_HD int scale16(uint32_t r16, int n) { return (int)((r16 * (uint32_t)n) >> 16); }
 
 // position of the k-th (0-based) set bit of x, k < popc(x)
-TET_HD int select_bit(uint64_t x, int k) {
+TET_HD int select_bit32(uint32_t v, int k) {
   int pos = 0;
-  uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
-  int c = popc(lo);
-  uint32_t v = lo;
-  if (k >= c) { k -= c; pos = 32; v = hi; }
-  c = popc(v & 0xFFFFu);
+  int c = popc(v & 0xFFFFu);
   if (k >= c) { k -= c; pos += 16; v >>= 16; }
   c = popc(v & 0xFFu);
   if (k >= c) { k -= c; pos += 8; v >>= 8; }
@@ -120,15 +122,30 @@ TET_HD int select_bit(uint64_t x, int k) {
   if (k >= c) { pos += 1; }
   return pos;
 }
+TET_HD int select_bit(uint64_t x, int k) {
+  const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+  const int c = popc(lo);
+  const bool up = k >= c;
+  return select_bit32(up ? hi : lo, up ? k - c : k) + (up ? 32 : 0);
+}
 
-TET_HD int bag_draw(uint32_t& bag, int n_pieces, uint32_t key, uint64_t env) {
+// draw one piece from the bag with 16 random bits (bag <= 12 bits)
+TET_HD int bag_draw(uint32_t& bag, int n_pieces, uint32_t r16) {
   if (bag == 0) bag = (1u << n_pieces) - 1u;
-  int m = popc(bag);
-  uint32_t r = hash_env(key, env);
-  int k = (int)(((uint64_t)r * (uint64_t)(uint32_t)m) >> 32);
-  int p = select_bit((uint64_t)bag, k);
-  bag &= ~(1u << p);
-  return p;
+  const int k = scale16(r16, popc(bag));
+  uint32_t v = bag;
+  int pos = 0;
+  int c = popc(v & 0xFFu);
+  if (k >= c) { pos = 8; v >>= 8; }
+  int kk = k >= c ? k - c : k;
+  c = popc(v & 0xFu);
+  if (kk >= c) { kk -= c; pos += 4; v >>= 4; }
+  c = popc(v & 0x3u);
+  if (kk >= c) { kk -= c; pos += 2; v >>= 2; }
+  c = (int)(v & 1u);
+  if (kk >= c) pos += 1;
+  bag &= ~(1u << pos);
+  return pos;
 }
 
 // ---- per-set table staged in LDS -------------------------------------------
@@ -228,8 +245,10 @@ TET_HD void board_features(const W (&col)[C], const int (&h)[C], int R, int& row
                            int& col_trans, int& holes, int& wells, int& row_trans, int& hole_depth) {
   const W wall = lowmask<W>(R + 4);  // walls of ones over every stored row (state.py:177-178)
   W hole_rows = 0;
-  int f1 = 0, f2 = 0, f4 = 0, f7 = 0;
-  int f5 = R - popc(col[C - 1]);  // state.py:190
+  int f1 = C;                      // one unconditional transition per column (state.py:194)
+  int f2 = 0, f4 = 0, f7 = 0;
+  int f5 = R - popc(col[C - 1]);   // state.py:190
+  int nh_left = 0;                 // holes of the left neighbour (the wall has none)
 #pragma unroll
   for (int i = 0; i < C; ++i) {
     const W x = col[i];
@@ -240,39 +259,35 @@ TET_HD void board_features(const W (&col)[C], const int (&h)[C], int R, int& row
     const int hL = (i == 0) ? R : h[i - 1];       // state.py:179 wall height = num_rows
     const int hR = (i == C - 1) ? R : h[i + 1];
     const W ho = (W)(~x & mh);                    // holes (state.py:210-213)
-    f2 += popc(ho);
+    const int nh = popc(ho);
+    f2 += nh;
     hole_rows |= ho;                              // state.py:215
-    f1 += 1 + popc((W)((x ^ ((x << 1) | 1)) & mh));  // state.py:194,206,219-220,242-243
+    f1 += popc((W)((x ^ ((x << 1) | 1)) & mh));   // state.py:206,219-220,242-243
     // hole depth: the top hole of each vertical run counts the filled cells above it
-    // (state.py:200,216,239)
-    W T = (TET_ABLATE & 16) ? (W)0 : (W)(ho & (x >> 1));
+    // (state.py:200,216,239); x[r+1] = 1 already implies r is below the column top
+    W T = (TET_ABLATE & 16) ? (W)0 : (W)(~x & (x >> 1));
     while (T != 0) {
       int r1 = bitlen(T);  // (index of the top remaining hole) + 1
       f7 += popc((W)(x >> r1));
       T = (W)(T & lowmask<W>(r1 - 1));
     }
-    // row transitions (state.py:203-204,223-226,246-248,253-254)
+    // row transitions (state.py:203-204,223-226,246-248,253-254).  Empty column: the
+    // filled cells of the left neighbour = hL - its holes (:254); otherwise max(hL-h, 0).
     f5 += popc((W)((x ^ L) & mh));
-    int dl = hL - hi;
-    f5 += (hi > 0) ? (dl > 0 ? dl : 0) : popc((W)(L & lowmask<W>(hL)));
+    const int dl = hL - hi;
+    f5 += (dl > 0 ? dl : 0) - ((hi == 0) ? nh_left : 0);
+    nh_left = nh;
     // wells (state.py:223-233 inside the column, :258-272 above it)
-    int top = hL < hR ? hL : hR;
-    W LR = (W)(L & Rr);
-    W win = (W)(ho & LR);
-    W open = (top > hi) ? (W)(lowmask<W>(top) & ~mh) : (W)0;
-    W wopen = (W)(LR & open);
-    W t;
-    if (wopen == open) {  // both neighbours solid over the whole open range
-      int d = top > hi ? top - hi : 0;
-      f4 += (d * (d + 1)) >> 1;
-      f4 += popc(win);
-      t = (W)(win & (win >> 1));
-    } else {
-      W w = (W)(win | wopen);
-      f4 += popc(w);
-      t = (W)(w & (w >> 1));
-    }
-    if (TET_ABLATE & 32) t = 0;
+    const int top = hL < hR ? hL : hR;
+    const int d = top > hi ? top - hi : 0;
+    const W open = (W)(lowmask<W>(d) << hi);      // rows hi .. top-1
+    const W LR = (W)(L & Rr);
+    const W win = (W)(ho & LR);
+    const W wopen = (W)(LR & open);
+    const bool solid = (wopen == open);           // both neighbours filled over the open range
+    const W w = solid ? win : (W)(win | wopen);
+    f4 += (solid ? ((d * (d + 1)) >> 1) : 0) + popc(w);
+    W t = (TET_ABLATE & 32) ? (W)0 : (W)(w & (w >> 1));
     while (t != 0) {  // runs of k consecutive rows add k(k+1)/2 in total
       f4 += popc(t);
       t = (W)(t & (t >> 1));
@@ -440,6 +455,7 @@ TET_HD int stamp_dynamic(W (&col)[C], const int (&h)[C], int c, uint32_t d, W (&
 // ---- one env step (game.py:82-92) --------------------------------------------
 struct StepOut {
   float obs[8];
+  int action;
   int reward;
   int done;
   int lines;
@@ -452,22 +468,29 @@ struct StepCfg {
   int R;
   int n_pieces;
   int auto_reset;
-  uint32_t key_step;   // hash_key(seed, 4*step_idx + 0): draw inside step (game.py:87)
-  uint32_t key_reset;  // hash_key(seed, 4*step_idx + 1): draw of the in-kernel reset (game.py:60)
-  float direct_by[8];  // state.py:49-50
+  uint32_t key_step;    // hash_key(seed, 4*step_idx + 0): piece draws of this step
+  uint32_t key_policy;  // hash_key(seed, 4*step_idx + 3): built-in uniform random policy
+  float direct_by[8];   // state.py:49-50
   int has_direct_by;
 };
 
-// `draw` = replay piece for the step draw (or -1: use the bag),
-// `draw_reset` = replay piece for the reset draw (or -1).
+// uniform random valid action (the random-rollout policy; also tetris_hip_policy_random)
+TET_HD int policy_random(uint32_t key_policy, uint32_t env, int n_valid) {
+  return scale16(hash_env(key_policy, env) >> 16, n_valid);
+}
+
+// `action` < 0 with use_policy: draw it with policy_random.  `draw` = replay piece for the
+// step draw (or -1: use the bag), `draw_reset` = replay piece for the reset draw (or -1).
 template <typename W, int C>
-TET_HD void env_step(W (&col)[C], uint64_t& meta, int action, const SetTable& tab, const StepCfg& cfg,
-                     uint64_t env, int draw, int draw_reset, StepOut& out) {
+TET_HD void env_step(W (&col)[C], uint64_t& meta, int action, bool use_policy, const SetTable& tab,
+                     const StepCfg& cfg, uint32_t env, int draw, int draw_reset, StepOut& out) {
   const int R = cfg.R;
   const uint64_t mask = meta_mask(meta);
   int piece = meta_piece(meta);
   uint32_t bag = meta_bag(meta);
   const int nv = popc(mask);
+  if (use_policy) action = policy_random(cfg.key_policy, env, nv);
+  out.action = action;
   out.invalid = (action < 0 || action >= nv) ? 1 : 0;
   if (out.invalid) {  // game.py:83 raises IndexError; the env is left untouched
 #pragma unroll
@@ -501,8 +524,10 @@ TET_HD void env_step(W (&col)[C], uint64_t& meta, int action, const SetTable& ta
 #pragma unroll
     for (int i = 0; i < 8; ++i) out.obs[i] *= cfg.direct_by[i];
   }
-  // game.py:87 next piece, :88 is_game_over for THAT piece
-  int np = draw >= 0 ? draw : bag_draw(bag, cfg.n_pieces, cfg.key_step, env);
+  // game.py:87 next piece, :88 is_game_over for THAT piece.  One hash feeds both draws of
+  // the step: high 16 bits the step draw, low 16 bits the reset draw.
+  const uint32_t rnd = hash_env(cfg.key_step, env);
+  int np = draw >= 0 ? draw : bag_draw(bag, cfg.n_pieces, rnd >> 16);
   uint64_t nmask = (TET_ABLATE & 2) ? (tab.fullmask[np] ^ (uint64_t)h[0])
                                     : valid_mask<W, C>(col, h, tab.orient[np], tab.fullmask[np], R);
   int nnv = popc(nmask);
@@ -513,7 +538,7 @@ TET_HD void env_step(W (&col)[C], uint64_t& meta, int action, const SetTable& ta
   if (done && cfg.auto_reset) {  // game.py:53-63 on the caller's behalf; the bag survives
 #pragma unroll
     for (int i = 0; i < C; ++i) col[i] = 0;
-    np = draw_reset >= 0 ? draw_reset : bag_draw(bag, cfg.n_pieces, cfg.key_reset, env);
+    np = draw_reset >= 0 ? draw_reset : bag_draw(bag, cfg.n_pieces, rnd & 0xFFFFu);
     nmask = tab.fullmask[np];
     nnv = popc(nmask);
   }

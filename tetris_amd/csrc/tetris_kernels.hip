@@ -50,7 +50,8 @@ __device__ __forceinline__ unsigned wave_sum(int value_bits, int v) {
 struct StepParams {
   void* cols;
   uint64_t* meta;
-  const int32_t* action;
+  const int32_t* action;   // NULL: built-in uniform random policy
+  int32_t* action_out;     // optional: the action each env played
   const uint8_t* stream;
   int32_t* cursor;
   int64_t stream_len;
@@ -61,8 +62,8 @@ struct StepParams {
   uint8_t* n_valid;
   uint8_t* piece_next;
   uint32_t* status;
-  int64_t B;
-  int64_t env_offset;
+  uint32_t B;
+  uint32_t env_offset;     // global env index of env 0 (mod 2^32)
   StepCfg cfg;
   SetTable tab;
 };
@@ -71,16 +72,16 @@ template <typename W, int C>
 __global__ __launch_bounds__(kBlock, TET_STEP_WAVES) void step_kernel(const StepParams p) {
   __shared__ SetTable tab;
   stage_table(tab, p.tab);
-  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
   const bool live = i < p.B;
   int invalid = 0, done = 0, lines = 0;
   if (live) {
     W* cols = static_cast<W*>(p.cols);
     W col[C];
 #pragma unroll
-    for (int c = 0; c < C; ++c) col[c] = cols[(int64_t)c * p.B + i];
+    for (int c = 0; c < C; ++c) col[c] = cols[(uint32_t)c * p.B + i];  // 32-bit offsets: saddr + voffset
     uint64_t meta = p.meta[i];
-    const int action = p.action[i];
+    const int action = p.action ? p.action[i] : -1;
     int draw = -1, draw_reset = -1, cur = 0;
     if (p.stream) {
       cur = p.cursor[i];
@@ -90,24 +91,26 @@ __global__ __launch_bounds__(kBlock, TET_STEP_WAVES) void step_kernel(const Step
       draw_reset = p.stream[r1 * p.B + i];
     }
     tet::StepOut out;
-    tet::env_step<W, C>(col, meta, action, tab, p.cfg, (uint64_t)(p.env_offset + i), draw, draw_reset, out);
+    tet::env_step<W, C>(col, meta, action, p.action == nullptr, tab, p.cfg, p.env_offset + i, draw, draw_reset,
+                        out);
     invalid = out.invalid;
+    float4* o4 = reinterpret_cast<float4*>(p.obs) + 2 * i;
+    o4[0] = make_float4(out.obs[0], out.obs[1], out.obs[2], out.obs[3]);
+    o4[1] = make_float4(out.obs[4], out.obs[5], out.obs[6], out.obs[7]);
     if (!invalid) {
 #pragma unroll
-      for (int c = 0; c < C; ++c) cols[(int64_t)c * p.B + i] = col[c];
+      for (int c = 0; c < C; ++c) cols[(uint32_t)c * p.B + i] = col[c];
       p.meta[i] = meta;
       done = out.done;
       lines = out.lines;
       if (p.stream) p.cursor[i] = cur + 1 + ((out.done && p.cfg.auto_reset) ? 1 : 0);
     }
-    float4* o4 = reinterpret_cast<float4*>(p.obs + i * 8);
-    o4[0] = make_float4(out.obs[0], out.obs[1], out.obs[2], out.obs[3]);
-    o4[1] = make_float4(out.obs[4], out.obs[5], out.obs[6], out.obs[7]);
     p.reward[i] = out.reward;
     p.done[i] = (uint8_t)out.done;
     p.lines[i] = (uint8_t)out.lines;
     p.n_valid[i] = (uint8_t)out.n_valid;
     if (p.piece_next) p.piece_next[i] = (uint8_t)out.piece;
+    if (p.action_out) p.action_out[i] = out.action;
   }
   if (p.status) {
     const unsigned n_inv = wave_sum(1, invalid);
@@ -115,8 +118,7 @@ __global__ __launch_bounds__(kBlock, TET_STEP_WAVES) void step_kernel(const Step
     const unsigned n_lines = wave_sum(3, lines);
     const unsigned n_steps = wave_sum(1, (live && !invalid) ? 1 : 0);
     if ((threadIdx.x & 63) == 0) {
-      const int64_t wave = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
-      uint4* slot = reinterpret_cast<uint4*>(p.status) + wave;
+      uint4* slot = reinterpret_cast<uint4*>(p.status) + (i >> 6);
       uint4 v = *slot;
       v.x += n_inv;
       v.y += n_done;
@@ -162,7 +164,7 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const ResetParams p) {
     piece = p.stream[r0 * p.B + i];
     p.cursor[i] = cur + 1;
   } else {
-    piece = tet::bag_draw(bag, p.n_pieces, p.key, (uint64_t)(p.env_offset + i));  // game.py:60
+    piece = tet::bag_draw(bag, p.n_pieces, tet::hash_env(p.key, (uint32_t)(p.env_offset + i)) >> 16);  // game.py:60
   }
   const uint64_t mask = tab.fullmask[piece];
   p.meta[i] = tet::meta_pack(mask, piece, bag);
@@ -289,8 +291,7 @@ __global__ __launch_bounds__(kBlock) void policy_random_kernel(const uint8_t* __
                                                                int64_t env_offset, int64_t B) {
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= B) return;
-  const uint32_t r = tet::hash_env(key, (uint64_t)(env_offset + i));
-  action[i] = (int32_t)(((uint64_t)r * (uint64_t)n_valid[i]) >> 32);
+  action[i] = tet::policy_random(key, (uint32_t)(env_offset + i), n_valid[i]);
 }
 
 template <typename W>
@@ -434,20 +435,21 @@ int tetris_hip_reset(const TetrisDesc* desc, void* cols, uint64_t* meta, const u
   return dispatch<LaunchReset>(desc, p, (hipStream_t)hip_stream);
 }
 
-int tetris_hip_step(const TetrisDesc* desc, void* cols, uint64_t* meta, const int32_t* action,
+int tetris_hip_step(const TetrisDesc* desc, void* cols, uint64_t* meta, const int32_t* action, int32_t* action_out,
                     const uint8_t* stream, int32_t* cursor, int64_t stream_len, float* obs, int32_t* reward,
                     uint8_t* done, uint8_t* lines, uint8_t* n_valid_next, uint8_t* piece_next, uint32_t* status,
                     int32_t auto_reset, uint64_t seed, uint64_t step_idx, int64_t env_offset, int64_t B,
                     void* hip_stream) {
   int rc = check_desc(desc);
   if (rc) return rc;
-  if (!cols || !meta || !action || !obs || !reward || !done || !lines || !n_valid_next) return TETRIS_E_NULL;
-  if (B <= 0) return TETRIS_E_BATCH;
+  if (!cols || !meta || !obs || !reward || !done || !lines || !n_valid_next) return TETRIS_E_NULL;
+  if (B <= 0 || B > 0x7FFFFFFF / (desc->num_columns * desc->word_bytes)) return TETRIS_E_BATCH;
   if (stream && (!cursor || stream_len <= 0)) return TETRIS_E_STREAM;
   StepParams p;
   p.cols = cols;
   p.meta = meta;
   p.action = action;
+  p.action_out = action_out;
   p.stream = stream;
   p.cursor = cursor;
   p.stream_len = stream_len;
@@ -458,13 +460,13 @@ int tetris_hip_step(const TetrisDesc* desc, void* cols, uint64_t* meta, const in
   p.n_valid = n_valid_next;
   p.piece_next = piece_next;
   p.status = status;
-  p.B = B;
-  p.env_offset = env_offset;
+  p.B = (uint32_t)B;
+  p.env_offset = (uint32_t)env_offset;
   p.cfg.R = desc->num_rows;
   p.cfg.n_pieces = desc->n_pieces;
   p.cfg.auto_reset = auto_reset;
   p.cfg.key_step = tet::hash_key(seed, step_idx * 4u + 0u);
-  p.cfg.key_reset = tet::hash_key(seed, step_idx * 4u + 1u);
+  p.cfg.key_policy = tet::hash_key(seed, step_idx * 4u + 3u);
   p.cfg.has_direct_by = desc->has_direct_by;
   for (int i = 0; i < 8; ++i) p.cfg.direct_by[i] = desc->direct_by[i];
   build_table(desc, &p.tab);

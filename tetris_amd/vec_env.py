@@ -83,7 +83,7 @@ class VecTetris:
             self.n_valid = torch.zeros(B, dtype=torch.uint8)
             self.piece = torch.zeros(B, dtype=torch.uint8)
             self.status = torch.zeros(int(self._lib.status_words(B)), dtype=torch.int32)  # [n_waves, 4]
-            self._action = torch.zeros(B, dtype=torch.int32)
+            self.action = torch.zeros(B, dtype=torch.int32)  # actions drawn by the built-in policy
         self.done = self._done.view(torch.bool)
         self._stream = None
         self._cursor = None
@@ -151,19 +151,24 @@ class VecTetris:
         return self._feats, self._nv_after
 
     # -- Tetris.step (game.py:82-92) ------------------------------------------------------
-    def step(self, action):
-        """``action`` [B] = index into each env's non-terminal placements.
+    def step(self, action=None):
+        """``action`` [B] = index into each env's non-terminal placements; ``None`` = every env
+        plays a uniform random valid action drawn inside the kernel (readable afterwards in
+        ``self.action``; identical to ``step(random_actions())``).
 
         Returns ``(obs [B,8] f32, reward [B] i32, done [B] bool, lines [B] u8)``.
         Out-of-range actions leave that env untouched and are counted; call
         :meth:`check` to turn them into the reference's IndexError."""
-        a = torch.as_tensor(action, device=self.device)
-        if a.shape != (self.batch_size,):
-            raise ValueError("action must be [batch_size]")
-        if a.dtype != torch.int32 or not a.is_contiguous():
-            a = a.to(torch.int32).contiguous()
+        a = None
+        if action is not None:
+            a = torch.as_tensor(action, device=self.device)
+            if a.shape != (self.batch_size,):
+                raise ValueError("action must be [batch_size]")
+            if a.dtype != torch.int32 or not a.is_contiguous():
+                a = a.to(torch.int32).contiguous()
         s, c, n = self._stream_args()
-        rc = self._lib.step(ctypes.byref(self.desc), _ptr(self.cols), _ptr(self.meta), _ptr(a), s, c, n,
+        rc = self._lib.step(ctypes.byref(self.desc), _ptr(self.cols), _ptr(self.meta), _ptr(a),
+                            _ptr(self.action) if a is None else None, s, c, n,
                             _ptr(self.obs), _ptr(self.reward), _ptr(self._done), _ptr(self.lines), _ptr(self.n_valid),
                             _ptr(self.piece), _ptr(self.status), int(self.auto_reset), self.seed, self.step_idx,
                             self.env_offset, self.batch_size, self._hip_stream())
@@ -173,7 +178,7 @@ class VecTetris:
 
     def random_actions(self, out=None):
         """Uniform random valid action per env (the random-rollout policy)."""
-        out = self._action if out is None else out
+        out = self.action if out is None else out
         rc = self._lib.policy_random(_ptr(self.n_valid), _ptr(out), self.seed, self.step_idx, self.env_offset,
                                      self.batch_size, self._hip_stream())
         self._lib.check(rc, "tetris_hip_policy_random")

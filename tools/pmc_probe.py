@@ -19,13 +19,13 @@ rows = int(os.environ.get("PROBE_ROWS", "20"))
 B = 1 << 20
 env = VecTetris(10, rows, B, device="cuda", auto_reset=True, seed=0)
 for t in range(150):  # reach the steady-state height distribution
-    env.step(env.random_actions())
+    env.step()
 torch.cuda.synchronize()
 for _ in range(3):
     env.refresh()     # reads 10 planes + meta, writes meta + n_valid
 torch.cuda.synchronize()
 for t in range(30):
-    env.step(env.random_actions())
+    env.step()
 torch.cuda.synchronize()
 env.check()
 print("probe done", env.stats())
