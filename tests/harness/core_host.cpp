@@ -17,6 +17,10 @@
 
 namespace {
 
+const uint8_t kHoleLut[tet::kHoleLutSize] = {
+#include "../../tetris_amd/csrc/tetris_hole_lut.inc"
+};
+
 template <typename W, int C>
 void step_impl(const TetrisDesc* desc, void* cols_, uint64_t* meta, const int32_t* action, int32_t* action_out,
                const uint8_t* stream,
@@ -47,7 +51,8 @@ void step_impl(const TetrisDesc* desc, void* cols_, uint64_t* meta, const int32_
       draw_reset = stream[r1 * B + i];
     }
     tet::StepOut out;
-    tet::env_step<W, C>(col, m, action ? action[i] : -1, action == nullptr, tab, cfg, (uint32_t)(env_offset + i),
+    tet::env_step<W, C>(col, m, action ? action[i] : -1, action == nullptr, tab, kHoleLut, cfg,
+                        (uint32_t)(env_offset + i),
                         draw, draw_reset, out);
     if (action_out) action_out[i] = out.action;
     if (!out.invalid) {
@@ -152,7 +157,7 @@ void after_impl(const TetrisDesc* desc, const void* cols_, const uint64_t* meta,
         const int k = tet::clear_lines<W, C>(nb, pbits, &eroded);
         tet::heights_of<W, C>(nb, nh);
         float f[8];
-        tet::bcts_features<W, C>(nb, nh, R, a, o.H, eroded, k, f);
+        tet::bcts_features<W, C>(nb, nh, R, kHoleLut, a, o.H, eroded, k, f);
         if (desc->has_direct_by)
           for (int q = 0; q < 8; ++q) f[q] *= desc->direct_by[q];
         // cross-check of the cached mask against the direct terminal test (state.py:36 after :33)

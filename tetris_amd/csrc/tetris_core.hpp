@@ -161,6 +161,9 @@ struct SetTable {
   uint64_t fullmask[kMaxPieces];   // all existing slots (every placement valid)
 };
 
+// hole-depth table (tools/gen_hole_lut.py): 8 KiB, staged in LDS by the kernels
+constexpr int kHoleLutSize = 1 << 13;
+
 constexpr uint64_t kLoop0Slots = 0x3333333333333333ull;  // slots with L = 0
 
 // action k -> slot, given the valid mask (game.py:69,83: index into the non-terminal
@@ -241,8 +244,9 @@ TET_HD int clear_lines(W (&col)[C], const W (&pbits)[4], int* eroded_cells) {
 
 // state.py:175-280 in closed form.  out = f0,f1,f2,f4,f5,f7.
 template <typename W, int C>
-TET_HD void board_features(const W (&col)[C], const int (&h)[C], int R, int& rows_with_holes,
-                           int& col_trans, int& holes, int& wells, int& row_trans, int& hole_depth) {
+TET_HD void board_features(const W (&col)[C], const int (&h)[C], int R, const uint8_t* hole_lut,
+                           int& rows_with_holes, int& col_trans, int& holes, int& wells, int& row_trans,
+                           int& hole_depth) {
   const W wall = lowmask<W>(R + 4);  // walls of ones over every stored row (state.py:177-178)
   W hole_rows = 0;
   int f1 = C;                      // one unconditional transition per column (state.py:194)
@@ -264,12 +268,18 @@ TET_HD void board_features(const W (&col)[C], const int (&h)[C], int R, int& row
     hole_rows |= ho;                              // state.py:215
     f1 += popc((W)((x ^ ((x << 1) | 1)) & mh));   // state.py:206,219-220,242-243
     // hole depth: the top hole of each vertical run counts the filled cells above it
-    // (state.py:200,216,239); x[r+1] = 1 already implies r is below the column top
-    W T = (TET_ABLATE & 16) ? (W)0 : (W)(~x & (x >> 1));
-    while (T != 0) {
-      int r1 = bitlen(T);  // (index of the top remaining hole) + 1
-      f7 += popc((W)(x >> r1));
-      T = (W)(T & lowmask<W>(r1 - 1));
+    // (state.py:200,216,239).  12-row chunks through the table: entry = A | u << 5 with u the
+    // run tops inside the chunk and A their filled cells above inside the chunk; the cells
+    // above the chunk count once per run top.
+    if (!(TET_ABLATE & 16)) {
+#pragma unroll
+      for (int k = 0; 12 * k < (int)(8 * sizeof(W)) - 1; ++k) {
+        if (k < 2 || 12 * k < R + 4) {  // rows beyond the stored ones are zero: entry 0 adds nothing
+          const uint32_t e = hole_lut[(uint32_t)(x >> (12 * k)) & 0x1FFFu];
+          const int above = (12 * (k + 1) < (int)(8 * sizeof(W))) ? popc((W)(x >> (12 * (k + 1)))) : 0;
+          f7 += (int)(e & 31u) + (int)(e >> 5) * above;
+        }
+      }
     }
     // row transitions (state.py:203-204,223-226,246-248,253-254).  Empty column: the
     // filled cells of the left neighbour = hL - its holes (:254); otherwise max(hL-h, 0).
@@ -287,8 +297,16 @@ TET_HD void board_features(const W (&col)[C], const int (&h)[C], int R, int& row
     const bool solid = (wopen == open);           // both neighbours filled over the open range
     const W w = solid ? win : (W)(win | wopen);
     f4 += (solid ? ((d * (d + 1)) >> 1) : 0) + popc(w);
+    // runs of k consecutive rows add k(k+1)/2 in total: level d counts the rows whose run
+    // extends d rows below them; three levels straight-line, deeper (rare) in a loop
     W t = (TET_ABLATE & 32) ? (W)0 : (W)(w & (w >> 1));
-    while (t != 0) {  // runs of k consecutive rows add k(k+1)/2 in total
+    f4 += popc(t);
+    t = (W)(t & (t >> 1));
+    f4 += popc(t);
+    t = (W)(t & (t >> 1));
+    f4 += popc(t);
+    t = (W)(t & (t >> 1));
+    while (t != 0) {
       f4 += popc(t);
       t = (W)(t & (t >> 1));
     }
@@ -303,10 +321,10 @@ TET_HD void board_features(const W (&col)[C], const int (&h)[C], int R, int& row
 
 // state.py:97-107: the eight BCTS features as float32
 template <typename W, int C>
-TET_HD void bcts_features(const W (&col)[C], const int (&h)[C], int R, int anchor_row, int H,
-                          int eroded_cells, int n_cleared, float (&f)[8]) {
+TET_HD void bcts_features(const W (&col)[C], const int (&h)[C], int R, const uint8_t* hole_lut, int anchor_row,
+                          int H, int eroded_cells, int n_cleared, float (&f)[8]) {
   int f0, f1, f2, f4, f5, f7;
-  board_features<W, C>(col, h, R, f0, f1, f2, f4, f5, f7);
+  board_features<W, C>(col, h, R, hole_lut, f0, f1, f2, f4, f5, f7);
   f[0] = (float)f0;
   f[1] = (float)f1;
   f[2] = (float)f2;
@@ -339,28 +357,32 @@ template <typename W, int C>
 TET_HD uint64_t valid_mask(const W (&col)[C], const int (&h)[C], const uint32_t (&tab)[4][3],
                            uint64_t fullmask, int R) {
   static_assert(C <= 10, "missing-cell rows are packed 3 bits per column into 32 bits");
-  uint32_t Xlo = 0, Xhi = 0, Mall = 0;
+  uint32_t Xlo = 0, Xhi = 0, Fall = 0;
 #pragma unroll
   for (int c = 0; c < C; ++c) {
     int sl = R - h[c];
     sl = sl < 4 ? sl : 4;
     sl = sl > 0 ? sl : 0;
-    const uint32_t th = (0x08CEFu >> (4 * sl)) & 0xFu;  // [s<1, s<2, s<3, s<4]
+    const uint32_t th = (0xFu << sl) & 0xFu;  // [s<1, s<2, s<3, s<4]
     if (c < 8) Xlo |= th << (4 * c);
     else Xhi |= th << (4 * (c - 8));
-    const uint32_t q = (uint32_t)(col[c] >> (R - 3)) & 7u;  // cells of rows R-3..R-1
-    Mall |= (q ^ 7u) << (3 * c);                            // missing cells
+    Fall |= ((uint32_t)(col[c] >> (R - 3)) & 7u) << (3 * c);  // cells of rows R-3..R-1
   }
+  const uint32_t Mall = ~Fall;  // missing cells, 3 bits per column
   int lo[3], hi[3];
   uint32_t single[3];
 #pragma unroll
   for (int t = 0; t < 3; ++t) {
-    const uint32_t m = (Mall >> t) & 0x09249249u;  // bit 3c: column c misses row R-3+t
+    const uint32_t m = (Mall >> t) & (0x09249249u & ((1u << (3 * C)) - 1u));  // bit 3c: column c misses row R-3+t
     // (a row of a reachable board is never full, so m != 0)
     lo[t] = m ? (__builtin_ctz(m) * 11) >> 5 : 0;          // /3
     hi[t] = m ? ((31 - __builtin_clz(m)) * 11) >> 5 : 31;
     single[t] = (lo[t] == hi[t]) ? (1u << lo[t]) : 0u;
   }
+  // vertical Straight rescued by two cleared rows: rows R-2 and R-1 both miss exactly column cc
+  const bool two = (single[1] & single[2]) != 0;
+  const uint32_t r2lo = (two && lo[1] < 8) ? (1u << (4 * lo[1])) : 0u;
+  const uint32_t r2hi = (two && lo[1] >= 8) ? (1u << (4 * (lo[1] - 8))) : 0u;
   uint32_t mlo = 0, mhi = 0;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -390,21 +412,15 @@ TET_HD uint64_t valid_mask(const W (&col)[C], const int (&h)[C], const uint32_t 
       const uint32_t iv = ((1u << len) - 1u) << c0;
       r1 |= (f & 1u) ? iv : 0u;
     }
-    uint32_t r2 = 0;
-    if ((rw >> 10) & 1u) {  // vertical Straight: any of its three lower rows / both of R-2, R-1
-      r1 = single[0] | single[1] | single[2];
-      r2 = single[1] & single[2];
-    }
+    const bool vert4 = (rw >> 10) & 1u;  // vertical Straight: any of its three lower rows
+    if (vert4) r1 = single[0] | single[1] | single[2];
+    const uint32_t b0 = vert4 ? r2lo : 0u, b1 = vert4 ? r2hi : 0u;
     // spread bit c -> bit 4c
-    uint32_t a0 = r1 & 0xFFu, b0 = r2 & 0xFFu;
+    uint32_t a0 = r1 & 0xFFu;
     a0 = (a0 | (a0 << 12)) & 0x000F000Fu;
     a0 = (a0 | (a0 << 6)) & 0x03030303u;
     a0 = (a0 | (a0 << 3)) & 0x11111111u;
-    b0 = (b0 | (b0 << 12)) & 0x000F000Fu;
-    b0 = (b0 | (b0 << 6)) & 0x03030303u;
-    b0 = (b0 | (b0 << 3)) & 0x11111111u;
     const uint32_t a1 = ((r1 >> 8) & 1u) | (((r1 >> 9) & 1u) << 4);
-    const uint32_t b1 = ((r2 >> 8) & 1u) | (((r2 >> 9) & 1u) << 4);
     const uint32_t vlo = (~i1lo | (~(i2lo & ~b0) & a0)) & 0x11111111u;
     const uint32_t vhi = (~i1hi | (~(i2hi & ~b1) & a1)) & 0x11111111u;
     mlo |= vlo << k;  // slot 4c + 2L + o with k = 2L + o
@@ -483,7 +499,8 @@ TET_HD int policy_random(uint32_t key_policy, uint32_t env, int n_valid) {
 // step draw (or -1: use the bag), `draw_reset` = replay piece for the reset draw (or -1).
 template <typename W, int C>
 TET_HD void env_step(W (&col)[C], uint64_t& meta, int action, bool use_policy, const SetTable& tab,
-                     const StepCfg& cfg, uint32_t env, int draw, int draw_reset, StepOut& out) {
+                     const uint8_t* hole_lut, const StepCfg& cfg, uint32_t env, int draw, int draw_reset,
+                     StepOut& out) {
   const int R = cfg.R;
   const uint64_t mask = meta_mask(meta);
   int piece = meta_piece(meta);
@@ -519,7 +536,7 @@ TET_HD void env_step(W (&col)[C], uint64_t& meta, int action, bool use_policy, c
 #pragma unroll
     for (int i = 0; i < 8; ++i) out.obs[i] = (float)h[i];
   } else
-  bcts_features<W, C>(col, h, R, a, oH, eroded, k, out.obs);  // game.py:91
+  bcts_features<W, C>(col, h, R, hole_lut, a, oH, eroded, k, out.obs);  // game.py:91
   if (cfg.has_direct_by) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) out.obs[i] *= cfg.direct_by[i];

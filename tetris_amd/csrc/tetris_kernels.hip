@@ -5,6 +5,7 @@
 // No dense contraction anywhere -> no MFMA; the path is HBM-streaming integer
 // bit work (popcount / clz / shifts) with the per-set piece table staged in LDS.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/tetris_hip.h"
@@ -27,6 +28,17 @@ constexpr int kBlock = 256;
 #endif
 
 // ---- kernels ------------------------------------------------------------------
+
+// hole-depth table (8 KiB; tools/gen_hole_lut.py), copied to LDS by the kernels that compute features
+__device__ const uint8_t kHoleLut[tet::kHoleLutSize] = {
+#include "tetris_hole_lut.inc"
+};
+
+__device__ __forceinline__ void stage_hole_lut(uint8_t* lds) {
+  const uint4* src = reinterpret_cast<const uint4*>(kHoleLut);
+  uint4* dst = reinterpret_cast<uint4*>(lds);
+  for (int t = threadIdx.x; t < tet::kHoleLutSize / 16; t += blockDim.x) dst[t] = src[t];
+}
 
 __device__ __forceinline__ void stage_table(SetTable& lds, const SetTable& arg) {
   const uint32_t* src = reinterpret_cast<const uint32_t*>(&arg);
@@ -68,42 +80,80 @@ struct StepParams {
   SetTable tab;
 };
 
+// Everything one lane reads for one env, fetched one tile ahead of the compute.
+template <typename W, int C>
+struct StepInputs {
+  W col[C];
+  uint64_t meta;
+  int action;
+  int draw, draw_reset, cursor;
+  uint4 status;
+};
+
+template <typename W, int C>
+__device__ __forceinline__ void load_inputs(const StepParams& p, uint32_t i, StepInputs<W, C>& in) {
+  const W* cols = static_cast<const W*>(p.cols);
+  const uint32_t ii = i < p.B ? i : 0;
+#pragma unroll
+  for (int c = 0; c < C; ++c) in.col[c] = cols[(uint32_t)c * p.B + ii];  // 32-bit offsets: saddr + voffset
+  in.meta = p.meta[ii];
+  in.action = p.action ? p.action[ii] : -1;
+  in.draw = -1;
+  in.draw_reset = -1;
+  in.cursor = 0;
+  if (p.stream) {
+    in.cursor = p.cursor[ii];
+    int64_t r0 = in.cursor < p.stream_len ? in.cursor : p.stream_len - 1;
+    int64_t r1 = in.cursor + 1 < p.stream_len ? in.cursor + 1 : p.stream_len - 1;
+    in.draw = p.stream[r0 * p.B + ii];
+    in.draw_reset = p.stream[r1 * p.B + ii];
+  }
+  in.status = make_uint4(0, 0, 0, 0);
+  if (p.status) in.status = reinterpret_cast<const uint4*>(p.status)[i >> 6];  // this wave's counter slot (allocated per tile)
+}
+
+// One tile of 256 envs per workgroup.  (A persistent grid-stride variant that prefetches the
+// next tile was measured and is slower: the kernel is bound by integer-VALU issue, not by
+// exposed memory latency, and the prefetch registers cost occupancy.)
 template <typename W, int C>
 __global__ __launch_bounds__(kBlock, TET_STEP_WAVES) void step_kernel(const StepParams p) {
   __shared__ SetTable tab;
-  stage_table(tab, p.tab);
+  __shared__ __attribute__((aligned(16))) uint8_t hole_lut[tet::kHoleLutSize];
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
   const bool live = i < p.B;
+  // Issue every global load of this lane first (board, meta, action, counters, its share of the
+  // two tables) so that one memory latency covers them all; only then fill LDS and barrier.
+  StepInputs<W, C> in;
+  load_inputs<W, C>(p, i, in);
+  {
+    static_assert(tet::kHoleLutSize == kBlock * 32, "two 16-byte pieces of the table per lane");
+    static_assert(sizeof(SetTable) / 4 <= kBlock, "one table word per lane");
+    const uint4* lsrc = reinterpret_cast<const uint4*>(kHoleLut);
+    const uint4 l0 = lsrc[threadIdx.x], l1 = lsrc[threadIdx.x + kBlock];
+    const uint32_t* tsrc = reinterpret_cast<const uint32_t*>(&p.tab);
+    const uint32_t tw = threadIdx.x < sizeof(SetTable) / 4 ? tsrc[threadIdx.x] : 0u;
+    reinterpret_cast<uint4*>(hole_lut)[threadIdx.x] = l0;
+    reinterpret_cast<uint4*>(hole_lut)[threadIdx.x + kBlock] = l1;
+    if (threadIdx.x < sizeof(SetTable) / 4) reinterpret_cast<uint32_t*>(&tab)[threadIdx.x] = tw;
+    __syncthreads();
+  }
+  W* cols = static_cast<W*>(p.cols);
   int invalid = 0, done = 0, lines = 0;
   if (live) {
-    W* cols = static_cast<W*>(p.cols);
-    W col[C];
-#pragma unroll
-    for (int c = 0; c < C; ++c) col[c] = cols[(uint32_t)c * p.B + i];  // 32-bit offsets: saddr + voffset
-    uint64_t meta = p.meta[i];
-    const int action = p.action ? p.action[i] : -1;
-    int draw = -1, draw_reset = -1, cur = 0;
-    if (p.stream) {
-      cur = p.cursor[i];
-      int64_t r0 = cur < p.stream_len ? cur : p.stream_len - 1;
-      int64_t r1 = cur + 1 < p.stream_len ? cur + 1 : p.stream_len - 1;
-      draw = p.stream[r0 * p.B + i];
-      draw_reset = p.stream[r1 * p.B + i];
-    }
     tet::StepOut out;
-    tet::env_step<W, C>(col, meta, action, p.action == nullptr, tab, p.cfg, p.env_offset + i, draw, draw_reset,
-                        out);
+    tet::env_step<W, C>(in.col, in.meta, in.action, p.action == nullptr, tab, hole_lut, p.cfg, p.env_offset + i,
+                        in.draw, in.draw_reset, out);
     invalid = out.invalid;
     float4* o4 = reinterpret_cast<float4*>(p.obs) + 2 * i;
     o4[0] = make_float4(out.obs[0], out.obs[1], out.obs[2], out.obs[3]);
     o4[1] = make_float4(out.obs[4], out.obs[5], out.obs[6], out.obs[7]);
     if (!invalid) {
 #pragma unroll
-      for (int c = 0; c < C; ++c) cols[(uint32_t)c * p.B + i] = col[c];
-      p.meta[i] = meta;
+      for (int c = 0; c < C; ++c) cols[(uint32_t)c * p.B + i] = in.col[c];
+      p.meta[i] = in.meta;
       done = out.done;
       lines = out.lines;
-      if (p.stream) p.cursor[i] = cur + 1 + ((out.done && p.cfg.auto_reset) ? 1 : 0);
+      if (p.stream) p.cursor[i] = in.cursor + 1 + ((out.done && p.cfg.auto_reset) ? 1 : 0);
     }
     p.reward[i] = out.reward;
     p.done[i] = (uint8_t)out.done;
@@ -118,13 +168,12 @@ __global__ __launch_bounds__(kBlock, TET_STEP_WAVES) void step_kernel(const Step
     const unsigned n_lines = wave_sum(3, lines);
     const unsigned n_steps = wave_sum(1, (live && !invalid) ? 1 : 0);
     if ((threadIdx.x & 63) == 0) {
-      uint4* slot = reinterpret_cast<uint4*>(p.status) + (i >> 6);
-      uint4 v = *slot;
+      uint4 v = in.status;
       v.x += n_inv;
       v.y += n_done;
       v.z += n_lines;
       v.w += n_steps;
-      *slot = v;
+      reinterpret_cast<uint4*>(p.status)[i >> 6] = v;
     }
   }
 }
@@ -220,6 +269,8 @@ struct AfterParams {
 template <typename W, int C>
 __global__ __launch_bounds__(kBlock) void afterstates_kernel(const AfterParams p) {
   __shared__ SetTable tab;
+  __shared__ __attribute__((aligned(16))) uint8_t hole_lut[tet::kHoleLutSize];
+  stage_hole_lut(hole_lut);
   stage_table(tab, p.tab);
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= p.B) return;
@@ -253,7 +304,7 @@ __global__ __launch_bounds__(kBlock) void afterstates_kernel(const AfterParams p
       const int k = tet::clear_lines<W, C>(nb, pbits, &eroded);
       tet::heights_of<W, C>(nb, nh);
       float f[8];
-      tet::bcts_features<W, C>(nb, nh, p.R, a, o.H, eroded, k, f);
+      tet::bcts_features<W, C>(nb, nh, p.R, hole_lut, a, o.H, eroded, k, f);
       if (p.has_direct_by) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) f[q] *= p.direct_by[q];
