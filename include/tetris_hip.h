@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define TETRIS_HIP_ABI_VERSION 2
+#define TETRIS_HIP_ABI_VERSION 3
 
 #define TETRIS_MAX_PIECES 12
 #define TETRIS_MAX_COLUMNS 10
@@ -60,7 +60,8 @@ enum {
   TETRIS_E_ROWS = -4,        /* num_rows outside [4, 59] */
   TETRIS_E_PIECES = -5,      /* bad piece list */
   TETRIS_E_BATCH = -6,       /* B <= 0 or B * num_columns * word_bytes >= 2^31 */
-  TETRIS_E_STREAM = -7       /* replay stream given without cursor / length */
+  TETRIS_E_STREAM = -7,      /* replay stream given without cursor / length */
+  TETRIS_E_STRIDE = -8       /* afterstate strides not multiples of 4 floats / too small */
 };
 
 /* Constructor arguments of game.Tetris (game.py:21-23) that shape the kernels. */
@@ -141,16 +142,18 @@ int tetris_hip_step(const TetrisDesc* desc, void* cols, uint64_t* meta, const in
 /*
  * Tetris.get_after_states (game.py:67-80): BCTS features of every placement
  * of the current piece.
- *  feats     : float32[B][a_max][8], row k = k-th NON-terminal placement
- *              (rows >= n_valid are zero)
+ *  feats     : float32, row k of env i at feats + i*env_stride + k*row_stride (strides in
+ *              floats, multiples of 4): row k = k-th NON-terminal placement, rows >= n_valid
+ *              are zero.  env-major [B][a_max][8] = (a_max*8, 8); action-major
+ *              [a_max][B][8] = (8, B*8) writes coalesced and is ~2x faster.
  *  n_valid   : uint8[B]
- *  feats_all : float32[B][a_max][8] or NULL: every placement in raw order
+ *  feats_all : same layout or NULL: every placement in raw order
  *              (include_terminal=True, game.py:74-78)
  *  n_all     : uint8[B] or NULL
  */
 int tetris_hip_afterstates(const TetrisDesc* desc, const void* cols, const uint64_t* meta,
                            float* feats, uint8_t* n_valid, float* feats_all, uint8_t* n_all,
-                           int64_t B, void* hip_stream);
+                           int64_t env_stride, int64_t row_stride, int64_t B, void* hip_stream);
 
 /* uniform random valid action per env: floor(u * n_valid), u from the
  * counter-based hash (the probe policy of SURVEY section 6 / example_play) */

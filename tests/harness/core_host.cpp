@@ -125,7 +125,7 @@ void refresh_impl(const TetrisDesc* desc, const void* cols_, uint64_t* meta, uin
 
 template <typename W, int C>
 void after_impl(const TetrisDesc* desc, const void* cols_, const uint64_t* meta, float* feats, uint8_t* n_valid,
-                float* feats_all, uint8_t* n_all, int64_t B) {
+                float* feats_all, uint8_t* n_all, int64_t env_stride, int64_t rs, int64_t B) {
   tet::SetTable tab;
   tet::build_table(desc, &tab);
   const W* cols = static_cast<const W*>(cols_);
@@ -138,38 +138,36 @@ void after_impl(const TetrisDesc* desc, const void* cols_, const uint64_t* meta,
     const int piece = tet::meta_piece(meta[i]);
     const uint64_t full = tab.fullmask[piece];
     const uint64_t valid = tet::meta_mask(meta[i]) & full;
-    float* out_valid = feats + i * (int64_t)a_max * 8;
-    float* out_all = feats_all ? feats_all + i * (int64_t)a_max * 8 : nullptr;
-    memset(out_valid, 0, sizeof(float) * a_max * 8);
-    if (out_all) memset(out_all, 0, sizeof(float) * a_max * 8);
-    const int nv = tet::popc(valid), na = tet::popc(full);
-    for (int lo = 0; lo < 4; ++lo) {
-      const tet::Orient o = tet::unpack_orient(tab.orient[piece][lo][0]);
-      if (!o.exists) continue;
-      for (int c = 0; c < C; ++c) {
-        const int s = 4 * c + lo;
-        if (!((full >> s) & 1)) continue;
-        W nb[C];
-        W pbits[4];
-        int nh[C];
-        const int a = tet::stamp_static<W, C>(col, h, c, o, nb, pbits);
-        int eroded = 0;
-        const int k = tet::clear_lines<W, C>(nb, pbits, &eroded);
-        tet::heights_of<W, C>(nb, nh);
-        float f[8];
-        tet::bcts_features<W, C>(nb, nh, R, kHoleLut, a, o.H, eroded, k, f);
-        if (desc->has_direct_by)
-          for (int q = 0; q < 8; ++q) f[q] *= desc->direct_by[q];
-        // cross-check of the cached mask against the direct terminal test (state.py:36 after :33)
-        const bool terminal = (a + o.H - k) > R;
-        if (terminal == (bool)((valid >> s) & 1)) {  // fail loudly in the tests
-          n_valid[i] = 255;
-          return;
-        }
-        if (out_all) memcpy(out_all + tet::row_of_slot(full, s) * 8, f, sizeof(f));
-        if ((valid >> s) & 1) memcpy(out_valid + tet::row_of_slot(valid, s) * 8, f, sizeof(f));
-      }
+    float* out_valid = feats + i * env_stride;
+    float* out_all = feats_all ? feats_all + i * env_stride : nullptr;
+    for (int k = 0; k < a_max; ++k) {
+      memset(out_valid + k * rs, 0, sizeof(float) * 8);
+      if (out_all) memset(out_all + k * rs, 0, sizeof(float) * 8);
     }
+    int nv = tet::popc(valid), na = tet::popc(full);
+    bool consistent = true;
+    tet::afterstates_env<W, C>(col, meta[i], tab, kHoleLut, R, [&](int s, float (&f)[8]) {
+      // cross-checks (test harness only): (1) the incremental features against the full
+      // evaluation of the same placement, (2) the cached mask against the direct terminal test
+      const tet::Orient o = tet::unpack_orient(tab.orient[piece][s & 3][0]);
+      W nb[C];
+      W pbits[4];
+      int nh[C];
+      const int a = tet::stamp_static<W, C>(col, h, s >> 2, o, nb, pbits);
+      int eroded = 0;
+      const int k = tet::clear_lines<W, C>(nb, pbits, &eroded);
+      tet::heights_of<W, C>(nb, nh);
+      float g[8];
+      tet::bcts_features<W, C>(nb, nh, R, kHoleLut, a, o.H, eroded, k, g);
+      for (int q = 0; q < 8; ++q) consistent = consistent && (g[q] == f[q]);
+      const bool terminal = (a + o.H - k) > R;  // state.py:36 after :33
+      consistent = consistent && (terminal != (bool)((valid >> s) & 1));
+      if (desc->has_direct_by)
+        for (int q = 0; q < 8; ++q) f[q] *= desc->direct_by[q];
+      if (out_all) memcpy(out_all + tet::row_of_slot(full, s) * rs, f, sizeof(float) * 8);
+      if ((valid >> s) & 1) memcpy(out_valid + tet::row_of_slot(valid, s) * rs, f, sizeof(float) * 8);
+    });
+    if (!consistent) nv = 255;  // fail loudly in the tests
     n_valid[i] = (uint8_t)nv;
     if (n_all) n_all[i] = (uint8_t)na;
   }
@@ -234,10 +232,12 @@ int tetris_host_refresh(const TetrisDesc* desc, const void* cols, uint64_t* meta
 }
 
 int tetris_host_afterstates(const TetrisDesc* desc, const void* cols, const uint64_t* meta, float* feats,
-                            uint8_t* n_valid, float* feats_all, uint8_t* n_all, int64_t B, void* unused) {
+                            uint8_t* n_valid, float* feats_all, uint8_t* n_all, int64_t env_stride,
+                            int64_t row_stride, int64_t B, void* unused) {
   (void)unused;
   return dispatch(desc, [&](auto w, auto c) {
-    after_impl<decltype(w), decltype(c)::value>(desc, cols, meta, feats, n_valid, feats_all, n_all, B);
+    after_impl<decltype(w), decltype(c)::value>(desc, cols, meta, feats, n_valid, feats_all, n_all, env_stride,
+                                                row_stride, B);
   });
 }
 

@@ -9,7 +9,7 @@ import os
 from . import build as _build
 
 MAX_PIECES = 12
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class TetrisDesc(ctypes.Structure):
@@ -44,7 +44,7 @@ SIGNATURES = {
     "tetris_hip_reset": [_dp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _u64, _u64, _i64, _i64, _vp],
     "tetris_hip_step": [_dp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _u64, _u64,
                         _i64, _i64, _vp],
-    "tetris_hip_afterstates": [_dp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
+    "tetris_hip_afterstates": [_dp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp],
     "tetris_hip_policy_random": [_vp, _vp, _u64, _u64, _i64, _i64, _vp],
     "tetris_hip_decode": [_dp, _vp, _vp, _vp, _i64, _vp],
     "tetris_hip_encode": [_dp, _vp, _vp, _i64, _vp],

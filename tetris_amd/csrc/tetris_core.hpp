@@ -25,6 +25,14 @@
 #define TET_ABLATE 0
 #endif
 
+// wave-uniform "does any active lane want this": lets code that only some pieces need be
+// skipped by the whole wavefront (one env per lane).  On the host build it is the lane itself.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define TET_WAVE_ANY(x) (__ballot((x)) != 0ull)
+#else
+#define TET_WAVE_ANY(x) (x)
+#endif
+
 namespace tet {
 
 constexpr int kMaxPieces = 12;   // pieces in one set (bag is 12 bits of meta)
@@ -242,7 +250,70 @@ TET_HD int clear_lines(W (&col)[C], const W (&pbits)[4], int* eroded_cells) {
   return k;
 }
 
-// state.py:175-280 in closed form.  out = f0,f1,f2,f4,f5,f7.
+// ---- per-column pieces of state.py:175-280 (closed forms of SURVEY App. B) ------------
+// Part that depends on the column alone: holes, column transitions, hole depth.
+template <typename W>
+TET_HD void col_own(W x, int hi, int R, const uint8_t* hole_lut, W& ho, int& nh, int& f1, int& f7) {
+  const W mh = lowmask<W>(hi);
+  ho = (W)(~x & mh);                               // holes (state.py:210-213)
+  nh = popc(ho);
+  f1 = popc((W)((x ^ ((x << 1) | 1)) & mh));       // state.py:206,219-220,242-243
+  // hole depth: the top hole of each vertical run counts the filled cells above it
+  // (state.py:200,216,239).  12-row chunks through the table: entry = A | u << 5 with u the
+  // run tops inside the chunk and A their filled cells above inside the chunk; the cells
+  // above the chunk count once per run top.
+  int d7 = 0;
+  if (!(TET_ABLATE & 16)) {
+#pragma unroll
+    for (int k = 0; 12 * k < (int)(8 * sizeof(W)) - 1; ++k) {
+      if (k < 2 || 12 * k < R + 4) {  // rows beyond the stored ones are zero: entry 0 adds nothing
+        const uint32_t e = hole_lut[(uint32_t)(x >> (12 * k)) & 0x1FFFu];
+        const int above = (12 * (k + 1) < (int)(8 * sizeof(W))) ? popc((W)(x >> (12 * (k + 1)))) : 0;
+        d7 += (int)(e & 31u) + (int)(e >> 5) * above;
+      }
+    }
+  }
+  f7 = d7;
+}
+
+// Row transitions of one column against its LEFT neighbour (state.py:203-204,223-226,
+// 246-248,253-254).  Empty column: the filled cells of the left neighbour = hL - its holes
+// (:254); otherwise max(hL-h, 0).
+template <typename W>
+TET_HD int col_rowtrans(W x, W L, int hi, int hL, int nh_left) {
+  const int dl = hL - hi;
+  return popc((W)((x ^ L) & lowmask<W>(hi))) + (dl > 0 ? dl : 0) - ((hi == 0) ? nh_left : 0);
+}
+
+// Cumulative wells of one column (state.py:223-233 inside the column, :258-272 above it).
+template <typename W>
+TET_HD int col_wells(W ho, W L, W Rr, int hi, int hL, int hR) {
+  const int top = hL < hR ? hL : hR;
+  const int d = top > hi ? top - hi : 0;
+  const W open = (W)(lowmask<W>(d) << hi);      // rows hi .. top-1
+  const W LR = (W)(L & Rr);
+  const W win = (W)(ho & LR);
+  const W wopen = (W)(LR & open);
+  const bool solid = (wopen == open);           // both neighbours filled over the open range
+  const W w = solid ? win : (W)(win | wopen);
+  int f4 = (solid ? ((d * (d + 1)) >> 1) : 0) + popc(w);
+  // runs of k consecutive rows add k(k+1)/2 in total: level d counts the rows whose run
+  // extends d rows below them; three levels straight-line, deeper (rare) in a loop
+  W t = (TET_ABLATE & 32) ? (W)0 : (W)(w & (w >> 1));
+  f4 += popc(t);
+  t = (W)(t & (t >> 1));
+  f4 += popc(t);
+  t = (W)(t & (t >> 1));
+  f4 += popc(t);
+  t = (W)(t & (t >> 1));
+  while (t != 0) {
+    f4 += popc(t);
+    t = (W)(t & (t >> 1));
+  }
+  return f4;
+}
+
+// state.py:175-280.  out = f0,f1,f2,f4,f5,f7.
 template <typename W, int C>
 TET_HD void board_features(const W (&col)[C], const int (&h)[C], int R, const uint8_t* hole_lut,
                            int& rows_with_holes, int& col_trans, int& holes, int& wells, int& row_trans,
@@ -255,61 +326,20 @@ TET_HD void board_features(const W (&col)[C], const int (&h)[C], int R, const ui
   int nh_left = 0;                 // holes of the left neighbour (the wall has none)
 #pragma unroll
   for (int i = 0; i < C; ++i) {
-    const W x = col[i];
-    const int hi = h[i];
-    const W mh = lowmask<W>(hi);
     const W L = (i == 0) ? wall : col[i - 1];
     const W Rr = (i == C - 1) ? wall : col[i + 1];
     const int hL = (i == 0) ? R : h[i - 1];       // state.py:179 wall height = num_rows
     const int hR = (i == C - 1) ? R : h[i + 1];
-    const W ho = (W)(~x & mh);                    // holes (state.py:210-213)
-    const int nh = popc(ho);
+    W ho;
+    int nh, d1, d7;
+    col_own<W>(col[i], h[i], R, hole_lut, ho, nh, d1, d7);
+    f1 += d1;
     f2 += nh;
+    f7 += d7;
     hole_rows |= ho;                              // state.py:215
-    f1 += popc((W)((x ^ ((x << 1) | 1)) & mh));   // state.py:206,219-220,242-243
-    // hole depth: the top hole of each vertical run counts the filled cells above it
-    // (state.py:200,216,239).  12-row chunks through the table: entry = A | u << 5 with u the
-    // run tops inside the chunk and A their filled cells above inside the chunk; the cells
-    // above the chunk count once per run top.
-    if (!(TET_ABLATE & 16)) {
-#pragma unroll
-      for (int k = 0; 12 * k < (int)(8 * sizeof(W)) - 1; ++k) {
-        if (k < 2 || 12 * k < R + 4) {  // rows beyond the stored ones are zero: entry 0 adds nothing
-          const uint32_t e = hole_lut[(uint32_t)(x >> (12 * k)) & 0x1FFFu];
-          const int above = (12 * (k + 1) < (int)(8 * sizeof(W))) ? popc((W)(x >> (12 * (k + 1)))) : 0;
-          f7 += (int)(e & 31u) + (int)(e >> 5) * above;
-        }
-      }
-    }
-    // row transitions (state.py:203-204,223-226,246-248,253-254).  Empty column: the
-    // filled cells of the left neighbour = hL - its holes (:254); otherwise max(hL-h, 0).
-    f5 += popc((W)((x ^ L) & mh));
-    const int dl = hL - hi;
-    f5 += (dl > 0 ? dl : 0) - ((hi == 0) ? nh_left : 0);
+    f5 += col_rowtrans<W>(col[i], L, h[i], hL, nh_left);
     nh_left = nh;
-    // wells (state.py:223-233 inside the column, :258-272 above it)
-    const int top = hL < hR ? hL : hR;
-    const int d = top > hi ? top - hi : 0;
-    const W open = (W)(lowmask<W>(d) << hi);      // rows hi .. top-1
-    const W LR = (W)(L & Rr);
-    const W win = (W)(ho & LR);
-    const W wopen = (W)(LR & open);
-    const bool solid = (wopen == open);           // both neighbours filled over the open range
-    const W w = solid ? win : (W)(win | wopen);
-    f4 += (solid ? ((d * (d + 1)) >> 1) : 0) + popc(w);
-    // runs of k consecutive rows add k(k+1)/2 in total: level d counts the rows whose run
-    // extends d rows below them; three levels straight-line, deeper (rare) in a loop
-    W t = (TET_ABLATE & 32) ? (W)0 : (W)(w & (w >> 1));
-    f4 += popc(t);
-    t = (W)(t & (t >> 1));
-    f4 += popc(t);
-    t = (W)(t & (t >> 1));
-    f4 += popc(t);
-    t = (W)(t & (t >> 1));
-    while (t != 0) {
-      f4 += popc(t);
-      t = (W)(t & (t >> 1));
-    }
+    f4 += col_wells<W>(ho, L, Rr, h[i], hL, hR);
   }
   rows_with_holes = popc(hole_rows);  // state.py:274-275
   col_trans = f1;
@@ -466,6 +496,168 @@ TET_HD int stamp_dynamic(W (&col)[C], const int (&h)[C], int c, uint32_t d, W (&
     col[i] |= add;
   }
   return a;
+}
+
+// ---- all afterstates of one env (game.py:67-80) -----------------------------------------
+// emit(slot, f[8]) is called for every existing placement of the current piece with the BCTS
+// features of its afterstate.  The per-column feature terms of the current board are computed
+// once; a placement that clears no line changes at most its footprint columns, so only those
+// (plus the wells of the left neighbour and the row transitions / wells of the right one) are
+// re-evaluated -- with the left column c static, all of that indexes registers statically.
+// Placements that do clear lines (rare) take the full path.
+template <typename W, int C, typename Emit>
+TET_HD void afterstates_env(const W (&col)[C], uint64_t meta, const SetTable& tab, const uint8_t* hole_lut, int R,
+                            Emit&& emit) {
+  int h[C];
+  heights_of<W, C>(col, h);
+  const W wall = lowmask<W>(R + 4);
+  const int piece = meta_piece(meta);
+  const uint64_t full = tab.fullmask[piece];
+  // per-column terms of the current board, packed to keep the register count down:
+  //   TA = col_trans (10 bits) | holes << 10 (10 bits) | row_trans << 20 (12 bits)
+  //   TB = wells (16 bits) | hole_depth << 16
+  // (field widths hold the whole-board sums for up to 60 stored rows x 10 columns)
+  W HO[C];
+  uint32_t TA[C], TB[C];
+  uint32_t sA = (uint32_t)C, sB = 0;  // column_transitions starts at one per column (state.py:194)
+  {
+    int nh_left = 0;
+#pragma unroll
+    for (int i = 0; i < C; ++i) {
+      const W L = (i == 0) ? wall : col[i - 1];
+      const W Rr = (i == C - 1) ? wall : col[i + 1];
+      const int hL = (i == 0) ? R : h[i - 1];
+      const int hR = (i == C - 1) ? R : h[i + 1];
+      int nh, e1, e7;
+      col_own<W>(col[i], h[i], R, hole_lut, HO[i], nh, e1, e7);
+      const int e5 = col_rowtrans<W>(col[i], L, h[i], hL, nh_left);
+      const int e4 = col_wells<W>(HO[i], L, Rr, h[i], hL, hR);
+      nh_left = nh;
+      TA[i] = (uint32_t)e1 | ((uint32_t)nh << 10) | ((uint32_t)e5 << 20);
+      TB[i] = (uint32_t)e4 | ((uint32_t)e7 << 16);
+      sA += TA[i];
+      sB += TB[i];
+    }
+  }
+  const int plast = popc(col[C - 1]);
+  uint64_t slow = 0;  // placements that clear lines: evaluated in full below
+#pragma unroll 1
+  for (int k = 0; k < 4; ++k) {
+    const Orient o = unpack_orient(tab.orient[piece][k][0]);
+    if (!o.exists) continue;
+    const bool u1 = TET_WAVE_ANY(o.w > 1), u2 = TET_WAVE_ANY(o.w > 2), u3 = TET_WAVE_ANY(o.w > 3);
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const int s = 4 * c + k;
+      if (!((full >> s) & 1)) continue;
+      int a = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (c + j < C) {
+          const int v = (j < o.w) ? h[c + j] - o.b[j] : 0;
+          a = v > a ? v : a;
+        }
+      W nb[4];
+      int nhh[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int nj = (j < o.w) ? o.n[j] : 0;
+        const W pb = (W)(lowmask<W>(nj) << (a + o.b[j]));
+        nb[j] = (c + j < C) ? (W)(col[c + j] | pb) : (W)0;
+        nhh[j] = (c + j < C) ? ((j < o.w) ? a + o.b[j] + o.n[j] : h[c + j]) : 0;
+      }
+      W F = (W)~(W)0;
+#pragma unroll
+      for (int i = 0; i < C; ++i) F &= (i >= c && i < c + 4) ? nb[i - c] : col[i];
+      if (F != 0) {
+        slow |= 1ull << s;
+        continue;
+      }
+      // clamp helpers keep every array index static and in range even in dead branches
+      constexpr int kz = 0;
+      const int cm1 = c >= 1 ? c - 1 : kz, cm2 = c >= 2 ? c - 2 : kz;
+      uint32_t dA = sA, dB = sB;
+      W hrows = 0;
+#pragma unroll
+      for (int i = 0; i < C; ++i)
+        if (i < c || i > c + 3) hrows |= HO[i];
+      if (c >= 1) {  // left neighbour: only its wells see the new column c
+        const W L2 = (c >= 2) ? col[cm2] : wall;
+        const int hL2 = (c >= 2) ? h[cm2] : R;
+        dB += (uint32_t)col_wells<W>(HO[cm1], L2, nb[0], h[cm1], hL2, nhh[0]) - (TB[cm1] & 0xFFFFu);
+      }
+      int nhprev = (c >= 1) ? (int)((TA[cm1] >> 10) & 1023u) : 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int i = c + j < C ? c + j : C - 1;
+        if (c + j < C) {
+          const bool fullre = (j == 0) || (j == 1 ? u1 : (j == 2 ? u2 : u3));
+          const bool part = !fullre && (j == 1 ? true : (j == 2 ? u1 : u2));
+          const int jm = j >= 1 ? j - 1 : 0, jp = j + 1 < 4 ? j + 1 : 3, ip = i + 1 < C ? i + 1 : C - 1;
+          const W L = (j == 0) ? ((c >= 1) ? col[cm1] : wall) : nb[jm];
+          const int hL = (j == 0) ? ((c >= 1) ? h[cm1] : R) : nhh[jm];
+          const W Rr = (c + j + 1 < C) ? ((j + 1 < 4) ? nb[jp] : col[ip]) : wall;
+          const int hR = (c + j + 1 < C) ? ((j + 1 < 4) ? nhh[jp] : h[ip]) : R;
+          if (fullre) {
+            W ho;
+            int nh, e1, e7;
+            col_own<W>(nb[j], nhh[j], R, hole_lut, ho, nh, e1, e7);
+            const int e5 = col_rowtrans<W>(nb[j], L, nhh[j], hL, nhprev);
+            const int e4 = col_wells<W>(ho, L, Rr, nhh[j], hL, hR);
+            dA += ((uint32_t)e1 | ((uint32_t)nh << 10) | ((uint32_t)e5 << 20)) - TA[i];
+            dB += ((uint32_t)e4 | ((uint32_t)e7 << 16)) - TB[i];
+            hrows |= ho;
+            nhprev = nh;
+          } else {
+            hrows |= HO[i];
+            if (part) {  // right neighbour of the widest footprint in this wave
+              const int e5 = col_rowtrans<W>(col[i], L, h[i], hL, nhprev);
+              const int e4 = col_wells<W>(HO[i], L, Rr, h[i], hL, hR);
+              dA += ((uint32_t)e5 << 20) - (TA[i] & 0xFFF00000u);
+              dB += (uint32_t)e4 - (TB[i] & 0xFFFFu);
+            }
+            nhprev = (int)((TA[i] >> 10) & 1023u);
+          }
+        }
+      }
+      if (c + 4 < C && u3) {  // right neighbour of a 4-wide footprint
+        const int i = c + 4 < C ? c + 4 : C - 1, ip = i + 1 < C ? i + 1 : C - 1;
+        const W Rr = (c + 5 < C) ? col[ip] : wall;
+        const int hR = (c + 5 < C) ? h[ip] : R;
+        dA += ((uint32_t)col_rowtrans<W>(col[i], nb[3], h[i], nhh[3], nhprev) << 20) - (TA[i] & 0xFFF00000u);
+        dB += (uint32_t)col_wells<W>(HO[i], nb[3], Rr, h[i], nhh[3], hR) - (TB[i] & 0xFFFFu);
+      }
+      const int lj = (C - 1 - c >= 0 && C - 1 - c < 4) ? C - 1 - c : 0;
+      const int pl = (C - 1 >= c && C - 1 < c + 4) ? popc(nb[lj]) : plast;
+      float f[8];
+      f[0] = (float)popc(hrows);
+      f[1] = (float)(dA & 1023u);
+      f[2] = (float)((dA >> 10) & 1023u);
+      f[3] = (float)a + 0.5f * (float)(o.H - 1) + 1.0f;
+      f[4] = (float)(dB & 0xFFFFu);
+      f[5] = (float)(R - pl + (int)(dA >> 20));
+      f[6] = 0.0f;
+      f[7] = (float)(dB >> 16);
+      emit(s, f);
+    }
+  }
+  while (slow != 0) {  // line-clearing placements (rare): full evaluation, state.py:33 onwards
+    const int s = bitlen(slow) - 1;
+    slow &= ~(1ull << s);
+    W fb[C];
+#pragma unroll
+    for (int i = 0; i < C; ++i) fb[i] = col[i];
+    W pbits[4];
+    int fh[C];
+    const uint32_t od = tab.orient[piece][s & 3][0];
+    const int aa = stamp_dynamic<W, C>(fb, h, s >> 2, od, pbits);
+    int eroded = 0;
+    const int kk = clear_lines<W, C>(fb, pbits, &eroded);
+    heights_of<W, C>(fb, fh);
+    float f[8];
+    bcts_features<W, C>(fb, fh, R, hole_lut, aa, (int)((od >> 3) & 7u), eroded, kk, f);
+    emit(s, f);
+  }
 }
 
 // ---- one env step (game.py:82-92) --------------------------------------------

@@ -257,6 +257,8 @@ struct AfterParams {
   float* feats_all;
   uint8_t* n_all;
   int64_t B;
+  int64_t env_stride;  // in floats: distance between the matrices of consecutive envs
+  int64_t row_stride;  // in floats: distance between consecutive feature rows of one env
   int32_t R;
   int32_t a_max;
   int32_t has_direct_by;
@@ -266,8 +268,11 @@ struct AfterParams {
 
 // game.py:67-80.  One lane per env walks the static slots in reference order;
 // the k-th non-terminal placement lands in feats[i][k].
+#ifndef TET_AFTER_WAVES
+#define TET_AFTER_WAVES 1
+#endif
 template <typename W, int C>
-__global__ __launch_bounds__(kBlock) void afterstates_kernel(const AfterParams p) {
+__global__ __launch_bounds__(kBlock, TET_AFTER_WAVES) void afterstates_kernel(const AfterParams p) {
   __shared__ SetTable tab;
   __shared__ __attribute__((aligned(16))) uint8_t hole_lut[tet::kHoleLutSize];
   stage_hole_lut(hole_lut);
@@ -276,60 +281,53 @@ __global__ __launch_bounds__(kBlock) void afterstates_kernel(const AfterParams p
   if (i >= p.B) return;
   const W* cols = static_cast<const W*>(p.cols);
   W col[C];
-  int h[C];
 #pragma unroll
   for (int c = 0; c < C; ++c) col[c] = cols[(int64_t)c * p.B + i];
-  tet::heights_of<W, C>(col, h);
   const uint64_t meta = p.meta[i];
   const int piece = tet::meta_piece(meta);
   const uint64_t full = tab.fullmask[piece];
   const uint64_t valid = tet::meta_mask(meta) & full;  // non-terminal slots (kept fresh by step/reset/refresh)
-  float* out_valid = p.feats + i * (int64_t)p.a_max * 8;
-  float* out_all = p.feats_all ? p.feats_all + i * (int64_t)p.a_max * 8 : nullptr;
+  // env-major ([B][a_max][8]: row_stride 8) scatters 32-byte rows 1 KiB apart; action-major
+  // ([a_max][B][8]: env_stride 8) lets a wave write 2 KiB contiguous per row -- 2x faster overall
+  float* out_valid = p.feats + i * p.env_stride;
+  float* out_all = p.feats_all ? p.feats_all + i * p.env_stride : nullptr;
+  const int64_t rs = p.row_stride;
   const int nv = tet::popc(valid), na = tet::popc(full);
-#pragma unroll 1
-  for (int lo = 0; lo < 4; ++lo) {
-    const tet::Orient o = tet::unpack_orient(tab.orient[piece][lo][0]);
-    if (!o.exists) continue;
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-      // the row of a placement follows the reference's enumeration order (tet::row_of_slot)
-      const int s = 4 * c + lo;
-      if (!((full >> s) & 1)) continue;
-      W nb[C];
-      W pbits[4];
-      int nh[C];
-      const int a = tet::stamp_static<W, C>(col, h, c, o, nb, pbits);
-      int eroded = 0;
-      const int k = tet::clear_lines<W, C>(nb, pbits, &eroded);
-      tet::heights_of<W, C>(nb, nh);
-      float f[8];
-      tet::bcts_features<W, C>(nb, nh, p.R, hole_lut, a, o.H, eroded, k, f);
-      if (p.has_direct_by) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) f[q] *= p.direct_by[q];
-      }
-      if (out_all) {
-        float4* d = reinterpret_cast<float4*>(out_all + tet::row_of_slot(full, s) * 8);
-        d[0] = make_float4(f[0], f[1], f[2], f[3]);
-        d[1] = make_float4(f[4], f[5], f[6], f[7]);
-      }
-      if ((valid >> s) & 1) {  // game.py:69
-        float4* d = reinterpret_cast<float4*>(out_valid + tet::row_of_slot(valid, s) * 8);
-        d[0] = make_float4(f[0], f[1], f[2], f[3]);
-        d[1] = make_float4(f[4], f[5], f[6], f[7]);
-      }
+  float sink = 0.f;
+  tet::afterstates_env<W, C>(col, meta, tab, hole_lut, p.R, [&](int s, float (&f)[8]) {
+    if (TET_ABLATE & 64) {  // timing experiment: no feature stores
+      sink += f[0] + f[1] + f[2] + f[3] + f[4] + f[5] + f[6] + f[7] + (float)s;
+      return;
     }
+    if (p.has_direct_by) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) f[q] *= p.direct_by[q];
+    }
+    // the row of a placement follows the reference's enumeration order (tet::row_of_slot)
+    if (out_all) {
+      float4* d = reinterpret_cast<float4*>(out_all + tet::row_of_slot(full, s) * rs);
+      d[0] = make_float4(f[0], f[1], f[2], f[3]);
+      d[1] = make_float4(f[4], f[5], f[6], f[7]);
+    }
+    if ((valid >> s) & 1) {  // game.py:69
+      float4* d = reinterpret_cast<float4*>(out_valid + tet::row_of_slot(valid, s) * rs);
+      d[0] = make_float4(f[0], f[1], f[2], f[3]);
+      d[1] = make_float4(f[4], f[5], f[6], f[7]);
+    }
+  });
+  if (TET_ABLATE & 64) {
+    out_valid[0] = sink;
+    return;
   }
   const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int k = nv; k < p.a_max; ++k) {
-    float4* d = reinterpret_cast<float4*>(out_valid + k * 8);
+    float4* d = reinterpret_cast<float4*>(out_valid + k * rs);
     d[0] = z;
     d[1] = z;
   }
   if (out_all)
     for (int k = na; k < p.a_max; ++k) {
-      float4* d = reinterpret_cast<float4*>(out_all + k * 8);
+      float4* d = reinterpret_cast<float4*>(out_all + k * rs);
       d[0] = z;
       d[1] = z;
     }
@@ -432,6 +430,7 @@ const char* tetris_hip_error_string(int code) {
     case TETRIS_E_PIECES: return "bad piece list";
     case TETRIS_E_BATCH: return "batch size must be positive";
     case TETRIS_E_STREAM: return "replay stream needs cursor and stream_len > 0";
+    case TETRIS_E_STRIDE: return "afterstate strides must be multiples of 4 floats and >= 8";
     default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown error";
   }
 }
@@ -525,7 +524,8 @@ int tetris_hip_step(const TetrisDesc* desc, void* cols, uint64_t* meta, const in
 }
 
 int tetris_hip_afterstates(const TetrisDesc* desc, const void* cols, const uint64_t* meta, float* feats,
-                           uint8_t* n_valid, float* feats_all, uint8_t* n_all, int64_t B, void* hip_stream) {
+                           uint8_t* n_valid, float* feats_all, uint8_t* n_all, int64_t env_stride,
+                           int64_t row_stride, int64_t B, void* hip_stream) {
   int rc = check_desc(desc);
   if (rc) return rc;
   if (!cols || !meta || !feats || !n_valid) return TETRIS_E_NULL;
@@ -538,6 +538,9 @@ int tetris_hip_afterstates(const TetrisDesc* desc, const void* cols, const uint6
   p.feats_all = feats_all;
   p.n_all = n_all;
   p.B = B;
+  if (env_stride % 4 || row_stride % 4 || env_stride < 8 || row_stride < 8) return TETRIS_E_STRIDE;
+  p.env_stride = env_stride;
+  p.row_stride = row_stride;
   p.R = desc->num_rows;
   p.a_max = desc->a_max;
   p.has_direct_by = desc->has_direct_by;

@@ -42,11 +42,17 @@ class DoneGather:
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.local_envs = int(local_envs)
         self._out = None
+        # gloo (CPU tests, or rehearsing ranks that share one GPU) moves device tensors through the host
+        self._via_cpu = dist.is_initialized() and dist.get_backend(group) == "gloo"
 
     def gather_bits(self, done, async_op=False):
         bits = pack_done_bits(done)
         if self.world == 1:
             return bits.unsqueeze(0), None
+        if self._via_cpu:
+            parts = [torch.empty(bits.numel(), dtype=torch.uint8) for _ in range(self.world)]
+            dist.all_gather(parts, bits.cpu(), group=self.group)
+            return torch.stack(parts).to(bits.device), None
         if self._out is None or self._out.device != bits.device:
             self._out = torch.empty((self.world, bits.numel()), dtype=torch.uint8, device=bits.device)
         work = dist.all_gather_into_tensor(self._out.view(-1), bits, group=self.group, async_op=async_op)
@@ -62,5 +68,9 @@ class DoneGather:
         """Sum of the env's counters (VecTetris.totals(), int64 [4]) over all ranks."""
         s = totals.clone()
         if self.world > 1:
+            if self._via_cpu:
+                c = s.cpu()
+                dist.all_reduce(c, op=dist.ReduceOp.SUM, group=self.group)
+                return c.to(s.device)
             dist.all_reduce(s, op=dist.ReduceOp.SUM, group=self.group)
         return s

@@ -34,12 +34,15 @@ class VecTetris:
                  device bag (parity runs against a recorded NumPy stream)
     env_offset   global index of env 0 (shards of one logical batch draw the
                  same pieces as the unsharded batch)
+    afterstate_layout  storage of the get_after_states matrices: "action_major"
+                 ([a_max, B, 8], coalesced writes, ~2x faster; returned as a [B, a_max, 8] view)
+                 or "env_major" (contiguous [B, a_max, 8])
 
     ``step`` returns views of buffers that the next ``step`` overwrites.
     """
 
     def __init__(self, num_columns, num_rows, batch_size, device="cuda", pieces="default", auto_reset=False,
-                 seed=0, feature_directions=None, piece_stream=None, env_offset=0):
+                 seed=0, feature_directions=None, piece_stream=None, env_offset=0, afterstate_layout="action_major"):
         self._lib = _lib.load()
         self.device = torch.device(device)
         if self.device.type != self._lib.device_type:
@@ -54,6 +57,9 @@ class VecTetris:
         self.seed = int(seed)
         self.env_offset = int(env_offset)
         self.feature_directions = feature_directions
+        if afterstate_layout not in ("action_major", "env_major"):
+            raise ValueError("afterstate_layout must be 'action_major' or 'env_major'")
+        self.afterstate_layout = afterstate_layout
         self.loss_reward, self.timestep_reward = -100, -1  # game.py:34-35 (baked into the kernel)
 
         ids = (ctypes.c_int32 * len(self.piece_names))(*[CATALOGUE.index(n) for n in self.piece_names])
@@ -133,22 +139,27 @@ class VecTetris:
         env i is its k-th non-terminal placement (= action k), rows >= n_valid
         are zero.  With ``include_terminal`` also ``(features_all, n_all)`` in
         raw enumeration order (game.py:74-78)."""
-        B = self.batch_size
+        B, A = self.batch_size, self.a_max
+        am = self.afterstate_layout == "action_major"
+        shape = (A, B, 8) if am else (B, A, 8)
+        env_stride, row_stride = (8, B * 8) if am else (A * 8, 8)
         if self._feats is None:
-            self._feats = torch.empty((B, self.a_max, 8), dtype=torch.float32, device=self.device)
+            self._feats = torch.empty(shape, dtype=torch.float32, device=self.device)
             self._nv_after = torch.empty(B, dtype=torch.uint8, device=self.device)
         fa = na = None
         if include_terminal:
             if self._feats_all is None:
-                self._feats_all = torch.empty((B, self.a_max, 8), dtype=torch.float32, device=self.device)
+                self._feats_all = torch.empty(shape, dtype=torch.float32, device=self.device)
                 self._n_all = torch.empty(B, dtype=torch.uint8, device=self.device)
             fa, na = self._feats_all, self._n_all
         rc = self._lib.afterstates(ctypes.byref(self.desc), _ptr(self.cols), _ptr(self.meta), _ptr(self._feats),
-                                   _ptr(self._nv_after), _ptr(fa), _ptr(na), B, self._hip_stream())
+                                   _ptr(self._nv_after), _ptr(fa), _ptr(na), env_stride, row_stride, B,
+                                   self._hip_stream())
         self._lib.check(rc, "tetris_hip_afterstates")
+        view = (lambda t: t.permute(1, 0, 2)) if am else (lambda t: t)
         if include_terminal:
-            return self._feats, self._nv_after, fa, na
-        return self._feats, self._nv_after
+            return view(self._feats), self._nv_after, view(fa), na
+        return view(self._feats), self._nv_after
 
     # -- Tetris.step (game.py:82-92) ------------------------------------------------------
     def step(self, action=None):
