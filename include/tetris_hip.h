@@ -144,8 +144,8 @@ int tetris_hip_step(const TetrisDesc* desc, void* cols, uint64_t* meta, const in
  * of the current piece.
  *  feats     : float32, row k of env i at feats + i*env_stride + k*row_stride (strides in
  *              floats, multiples of 4): row k = k-th NON-terminal placement, rows >= n_valid
- *              are zero.  env-major [B][a_max][8] = (a_max*8, 8); action-major
- *              [a_max][B][8] = (8, B*8) writes coalesced and is ~2x faster.
+ *              are zero.  env-major [B][a_max][8] = (a_max*8, 8) (fastest: a wave's
+ *              rows stay within one 72 KiB span); action-major [a_max][B][8] = (8, B*8).
  *  n_valid   : uint8[B]
  *  feats_all : same layout or NULL: every placement in raw order
  *              (include_terminal=True, game.py:74-78)

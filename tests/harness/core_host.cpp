@@ -51,7 +51,8 @@ void step_impl(const TetrisDesc* desc, void* cols_, uint64_t* meta, const int32_
       draw_reset = stream[r1 * B + i];
     }
     tet::StepOut out;
-    tet::env_step<W, C>(col, m, action ? action[i] : -1, action == nullptr, tab, kHoleLut, cfg,
+    W scratch[C];
+    tet::env_step<W, C>(col, m, action ? action[i] : -1, action == nullptr, tab, kHoleLut, scratch, 1, cfg,
                         (uint32_t)(env_offset + i),
                         draw, draw_reset, out);
     if (action_out) action_out[i] = out.action;

@@ -33,6 +33,13 @@
 #define TET_WAVE_ANY(x) (x)
 #endif
 
+// OR into a per-lane scratch word (LDS on the device: a single ds_or, no return value)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define TET_SCRATCH_OR(ptr, v) ((void)__hip_atomic_fetch_or((ptr), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
+#else
+#define TET_SCRATCH_OR(ptr, v) (*(ptr) |= (v))
+#endif
+
 namespace tet {
 
 constexpr int kMaxPieces = 12;   // pieces in one set (bag is 12 bits of meta)
@@ -498,6 +505,37 @@ TET_HD int stamp_dynamic(W (&col)[C], const int (&h)[C], int c, uint32_t d, W (&
   return a;
 }
 
+// The same placement through a per-lane scratch column array (LDS on the device; element i of
+// this lane at scratch[i * sstride]).  The runtime column index then addresses memory instead
+// of selecting among registers: 10 stores, 4 loads, 4 ORs, 10 loads replace ~150 VALU selects,
+// and only the four footprint heights are computed.  (The kernels are integer-VALU bound and
+// the LDS pipe is otherwise idle.)
+template <typename W, int C>
+TET_HD int stamp_scratch(W (&col)[C], W* scratch, int sstride, int c, uint32_t d, W (&pbits)[4]) {
+#pragma unroll
+  for (int i = 0; i < C; ++i) scratch[i * sstride] = col[i];
+  const int w = d & 7;
+  int a = 0;
+  int idx[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    idx[j] = (c + j < C ? c + j : C - 1) * sstride;
+    const int bj = (d >> (6 + 5 * j)) & 3;
+    const int v = bitlen(scratch[idx[j]]) - bj;
+    a = (j < w && v > a) ? v : a;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int bj = (d >> (6 + 5 * j)) & 3;
+    const int nj = (j < w) ? (int)((d >> (8 + 5 * j)) & 7) : 0;
+    pbits[j] = (W)(lowmask<W>(nj) << (a + bj));
+    TET_SCRATCH_OR(&scratch[idx[j]], pbits[j]);  // j >= w ORs zero (index clamped in range)
+  }
+#pragma unroll
+  for (int i = 0; i < C; ++i) col[i] = scratch[i * sstride];
+  return a;
+}
+
 // ---- all afterstates of one env (game.py:67-80) -----------------------------------------
 // emit(slot, f[8]) is called for every existing placement of the current piece with the BCTS
 // features of its afterstate.  The per-column feature terms of the current board are computed
@@ -691,8 +729,8 @@ TET_HD int policy_random(uint32_t key_policy, uint32_t env, int n_valid) {
 // step draw (or -1: use the bag), `draw_reset` = replay piece for the reset draw (or -1).
 template <typename W, int C>
 TET_HD void env_step(W (&col)[C], uint64_t& meta, int action, bool use_policy, const SetTable& tab,
-                     const uint8_t* hole_lut, const StepCfg& cfg, uint32_t env, int draw, int draw_reset,
-                     StepOut& out) {
+                     const uint8_t* hole_lut, W* scratch, int sstride, const StepCfg& cfg, uint32_t env, int draw,
+                     int draw_reset, StepOut& out) {
   const int R = cfg.R;
   const uint64_t mask = meta_mask(meta);
   int piece = meta_piece(meta);
@@ -718,9 +756,8 @@ TET_HD void env_step(W (&col)[C], uint64_t& meta, int action, bool use_policy, c
   const int oH = (od >> 3) & 7;
 
   int h[C];
-  heights_of<W, C>(col, h);
   W pbits[4];
-  const int a = stamp_dynamic<W, C>(col, h, c, od, pbits);  // tetromino.py get_after_states
+  const int a = stamp_scratch<W, C>(col, scratch, sstride, c, od, pbits);  // tetromino.py get_after_states
   int eroded = 0;
   const int k = (TET_ABLATE & 8) ? 0 : clear_lines<W, C>(col, pbits, &eroded);   // state.py:33
   heights_of<W, C>(col, h);

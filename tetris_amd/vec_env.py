@@ -34,15 +34,16 @@ class VecTetris:
                  device bag (parity runs against a recorded NumPy stream)
     env_offset   global index of env 0 (shards of one logical batch draw the
                  same pieces as the unsharded batch)
-    afterstate_layout  storage of the get_after_states matrices: "action_major"
-                 ([a_max, B, 8], coalesced writes, ~2x faster; returned as a [B, a_max, 8] view)
-                 or "env_major" (contiguous [B, a_max, 8])
+    afterstate_layout  storage of the get_after_states matrices: "env_major" (contiguous
+                 [B, a_max, 8], default, fastest on MI355X) or "action_major"
+                 ([a_max, B, 8] storage returned as a [B, a_max, 8] view)
+
 
     ``step`` returns views of buffers that the next ``step`` overwrites.
     """
 
     def __init__(self, num_columns, num_rows, batch_size, device="cuda", pieces="default", auto_reset=False,
-                 seed=0, feature_directions=None, piece_stream=None, env_offset=0, afterstate_layout="action_major"):
+                 seed=0, feature_directions=None, piece_stream=None, env_offset=0, afterstate_layout="env_major"):
         self._lib = _lib.load()
         self.device = torch.device(device)
         if self.device.type != self._lib.device_type:

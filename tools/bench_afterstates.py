@@ -15,7 +15,7 @@ import ctypes, subprocess  # noqa: E402
 rows = int(os.environ.get("ABL_ROWS", "20"))
 pieces = os.environ.get("ABL_PIECES", "default")
 B = int(os.environ.get("ABL_B", str(1 << 20)))
-layout = os.environ.get("ABL_LAYOUT", "action_major")
+layout = os.environ.get("ABL_LAYOUT", "env_major")
 env = VecTetris(10, rows, B, device="cuda", pieces=pieces, auto_reset=True, seed=0, afterstate_layout=layout)
 for t in range(150):
     env.step()
