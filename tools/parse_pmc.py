@@ -32,7 +32,8 @@ def main():
     fetch_dir, write_dir = sys.argv[1], sys.argv[2]
     B = 1 << 20
     word = int(os.environ.get("PROBE_WORD_BYTES", "4"))
-    out = {"envs": B, "unit_note": "FETCH_SIZE/WRITE_SIZE reported in KiB by rocprofv3"}
+    out = {"envs": B, "columns": 10, "rows": int(os.environ.get("PROBE_ROWS", "20")), "pieces": "default",
+           "unit_note": "FETCH_SIZE/WRITE_SIZE reported in KiB by rocprofv3"}
     f = load(fetch_dir, "FETCH_SIZE")
     w = load(write_dir, "WRITE_SIZE")
     known_read = B * (10 * word + 8)
