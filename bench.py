@@ -30,8 +30,8 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (guides: 8.0 TB/s; ~6.3 TB/s achievable)
 
 
-def algorithmic_bytes_per_env_step(C, word_bytes):
-    return 2 * C * word_bytes + 47
+def algorithmic_bytes_per_env_step(C, word_bytes, with_obs=True):
+    return 2 * C * word_bytes + (47 if with_obs else 15)  # 127/207 B, 95/175 B without obs
 
 
 def cpu_baseline(C, R, pieces, seconds=12.0):
@@ -90,6 +90,7 @@ def main():
     ap.add_argument("--pieces", default="default")
     ap.add_argument("--gather-every", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-obs", action="store_true", help="skip the observation output (uses 95 B / 175 B per env-step)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
 
@@ -112,7 +113,7 @@ def main():
 
     B = args.batch
     env = VecTetris(args.columns, args.rows, B, device=dev, pieces=args.pieces, auto_reset=True, seed=0,
-                    env_offset=rank * B)
+                    env_offset=rank * B, compute_obs=not args.no_obs)
     gather = DoneGather(B)
 
     def barrier():
@@ -159,7 +160,7 @@ def main():
     env.check()
 
     if rank == 0:
-        alg = algorithmic_bytes_per_env_step(args.columns, env.desc.word_bytes)
+        alg = algorithmic_bytes_per_env_step(args.columns, env.desc.word_bytes, not args.no_obs)
         achieved = alg * B / (k_ms * 1e-3) / 1e9
         out = {
             "metric": "env-steps/sec",
@@ -177,12 +178,12 @@ def main():
             "config": {"workload": "%d envs/GPU x %d GPU, %dx%d board, pieces=%s, uniform random valid actions, "
                                    "in-kernel auto-reset, device bag seed 0" % (B, world, args.columns, args.rows,
                                                                                 args.pieces),
-                       "envs_per_gpu": B, "board": "%dx%d" % (args.columns, args.rows), "pieces": args.pieces,
+                       "envs_per_gpu": B, "observation_output": not args.no_obs, "board": "%dx%d" % (args.columns, args.rows), "pieces": args.pieces,
                        "sharding": "env-index ranges, no data-path collective; RCCL gathers done counters every "
                                    "%d steps + done bitmask at the end" % args.gather_every},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": load_traffic(args.columns, args.rows, args.pieces, B),
+                         "traffic": None if args.no_obs else load_traffic(args.columns, args.rows, args.pieces, B),
                          "kernel": "step_kernel", "kernel_ms": k_ms, "algorithmic_bytes_per_env_step": alg},
             "episodes": totals[1], "lines_cleared": totals[2],
         }

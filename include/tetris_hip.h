@@ -121,7 +121,9 @@ int tetris_hip_reset(const TetrisDesc* desc, void* cols, uint64_t* meta, const u
  *                 plays a uniform random valid action (the same one
  *                 tetris_hip_policy_random would return for this seed / step_idx)
  *  action_out   : int32[B] or NULL: the action each env played
- *  obs          : float32[B][8]   observation of the chosen afterstate
+ *  obs          : float32[B][8]   observation of the chosen afterstate, or NULL to skip the
+ *                 feature computation (a caller that ran tetris_hip_afterstates already holds it:
+ *                 it is row `action` of that matrix)
  *  reward       : int32[B]        lines - 1 (- 100 when done)   game.py:86-90
  *  done         : uint8[B]
  *  lines        : uint8[B]
@@ -154,6 +156,20 @@ int tetris_hip_step(const TetrisDesc* desc, void* cols, uint64_t* meta, const in
 int tetris_hip_afterstates(const TetrisDesc* desc, const void* cols, const uint64_t* meta,
                            float* feats, uint8_t* n_valid, float* feats_all, uint8_t* n_all,
                            int64_t env_stride, int64_t row_stride, int64_t B, void* hip_stream);
+
+/*
+ * Tetris.get_best_policy / fitness (game.py:102-120) batched: linear evaluation
+ * sum_k features[k] * weights[k] (float32, left to right) of every placement.
+ *  weights     : HOST pointer to 8 floats (game.py:111-118 uses -24.04 -19.77 -13.08 -12.63
+ *                -10.49 -9.22 6.6 -1.61)
+ *  best_action : int32[B]  first non-terminal action of maximal fitness (-1: none)
+ *  best_value  : float32[B] or NULL
+ *  fitness_all : float32[B][a_max] or NULL: every placement in raw order, terminal
+ *                included (the domain of get_best_policy, game.py:103)
+ */
+int tetris_hip_policy_greedy(const TetrisDesc* desc, const void* cols, const uint64_t* meta,
+                             const float* weights, int32_t* best_action, float* best_value,
+                             float* fitness_all, int64_t B, void* hip_stream);
 
 /* uniform random valid action per env: floor(u * n_valid), u from the
  * counter-based hash (the probe policy of SURVEY section 6 / example_play) */

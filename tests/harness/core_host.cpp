@@ -35,6 +35,7 @@ void step_impl(const TetrisDesc* desc, void* cols_, uint64_t* meta, const int32_
   cfg.auto_reset = auto_reset;
   cfg.key_step = tet::hash_key(seed, step_idx * 4u + 0u);
   cfg.key_policy = tet::hash_key(seed, step_idx * 4u + 3u);
+  cfg.compute_obs = obs != nullptr;
   cfg.has_direct_by = desc->has_direct_by;
   for (int i = 0; i < 8; ++i) cfg.direct_by[i] = desc->direct_by[i];
   W* cols = static_cast<W*>(cols_);
@@ -61,7 +62,8 @@ void step_impl(const TetrisDesc* desc, void* cols_, uint64_t* meta, const int32_
       meta[i] = m;
       if (stream) cursor[i] = cur + 1 + ((out.done && auto_reset) ? 1 : 0);
     }
-    for (int k = 0; k < 8; ++k) obs[i * 8 + k] = out.obs[k];
+    if (obs)
+      for (int k = 0; k < 8; ++k) obs[i * 8 + k] = out.obs[k];
     reward[i] = out.reward;
     done[i] = (uint8_t)out.done;
     lines[i] = (uint8_t)out.lines;
@@ -250,6 +252,45 @@ int tetris_host_policy_random(const uint8_t* n_valid, int32_t* action, uint64_t 
     action[i] = tet::policy_random(key, (uint32_t)(env_offset + i), n_valid[i]);
   }
   return 0;
+}
+
+int tetris_host_policy_greedy(const TetrisDesc* desc, const void* cols_, const uint64_t* meta, const float* weights,
+                              int32_t* best_action, float* best_value, float* fitness_all, int64_t B, void* unused) {
+  (void)unused;
+  return dispatch(desc, [&](auto wt, auto ct) {
+    using W = decltype(wt);
+    constexpr int C = decltype(ct)::value;
+    tet::SetTable tab;
+    tet::build_table(desc, &tab);
+    float w[8];
+    for (int q = 0; q < 8; ++q) w[q] = weights[q];
+    const W* cols = static_cast<const W*>(cols_);
+    for (int64_t i = 0; i < B; ++i) {
+      W col[C];
+      for (int c = 0; c < C; ++c) col[c] = cols[(int64_t)c * B + i];
+      const int piece = tet::meta_piece(meta[i]);
+      const uint64_t full = tab.fullmask[piece];
+      const uint64_t valid = tet::meta_mask(meta[i]) & full;
+      float* fall = fitness_all ? fitness_all + i * desc->a_max : nullptr;
+      if (fall)
+        for (int k = 0; k < desc->a_max; ++k) fall[k] = 0.f;
+      float best = 0.f;
+      int best_row = -1;
+      tet::afterstates_env<W, C>(col, meta[i], tab, kHoleLut, desc->num_rows, [&](int s, float (&f)[8]) {
+        const float v = tet::fitness_of(f, w);
+        if (fall) fall[tet::row_of_slot(full, s)] = v;
+        if ((valid >> s) & 1) {
+          const int row = tet::row_of_slot(valid, s);
+          if (best_row < 0 || v > best || (v == best && row < best_row)) {
+            best = v;
+            best_row = row;
+          }
+        }
+      });
+      best_action[i] = best_row;
+      if (best_value) best_value[i] = best;
+    }
+  });
 }
 
 int tetris_host_version(void) { return TETRIS_HIP_ABI_VERSION; }

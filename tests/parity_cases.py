@@ -247,3 +247,81 @@ def mask_rescue_stress(device, orc, n_boards=1500, R=20, C=10, seed=0):
                               (out["heights"].max(axis=1) + out["n_cleared"] > R)).sum())
     assert n_rescued > 50, n_rescued
     return n_rescued
+
+
+def edge_geometries(device, orc):
+    """Smallest / largest row counts of each word size, odd batch sizes, every column count built."""
+    eps = 0
+    for C, R, pieces, B in [(10, 4, "default", 130), (10, 27, "standard7", 65), (10, 28, "standard7", 63),
+                            (10, 59, "default", 31), (6, 4, "standard7", 1), (8, 27, "default", 257),
+                            (6, 59, "standard7", 64)]:
+        eps += lockstep(device, orc, C, R, B, pieces, steps=90, seed=3, check_after_every=15)
+    assert eps > 0
+
+
+def step_without_obs(device, orc, B=300):
+    """compute_obs=False: identical dynamics, obs untouched; the skipped observation equals row
+    `action` of the get_after_states matrix (game.py:91 vs :70-72)."""
+    from tetris_amd import VecTetris
+    a = VecTetris(10, 20, B, device=device, auto_reset=True, seed=4)
+    b = VecTetris(10, 20, B, device=device, auto_reset=True, seed=4, compute_obs=False)
+    for t in range(60):
+        feats, nv = b.get_after_states()
+        obs, rew, done, lines = a.step()
+        _, rew2, done2, lines2 = b.step()
+        assert torch.equal(a.action, b.action) and torch.equal(rew, rew2) and torch.equal(done, done2)
+        assert torch.equal(a.cols, b.cols) and torch.equal(a.meta, b.meta) and not b.obs.any()
+        picked = feats[torch.arange(B, device=feats.device), b.action.long()]
+        assert torch.equal(picked, obs)
+
+
+def greedy_policy(device, orc, golden_dir, B=400):
+    """tetris_hip_policy_greedy vs (a) float32 left-to-right fitness of the oracle's features and
+    (b) the get_best_policy vectors recorded from the reference (g6)."""
+    from tetris_amd import VecTetris
+    from tetris_amd.tetromino import CATALOGUE
+    w32 = np.array(VecTetris.BCTS_WEIGHTS, np.float32)
+
+    def fit(feats):  # game.py:109-118 under NumPy >= 2: float32 products and sums, left to right
+        acc = feats[..., 0] * w32[0]
+        for q in range(1, 8):
+            acc = (acc + feats[..., q] * w32[q]).astype(np.float32)
+        return acc
+
+    env = VecTetris(10, 20, B, device=device, pieces="standard7", auto_reset=True, seed=8)
+    ref = orc.OracleVecEnv(10, 20, B, pieces="standard7", auto_reset=True, seed=8)
+    for t in range(40):
+        ba, bv, fa = env.greedy_actions(include_fitness=True)
+        rf, rnv, rfa, rna = ref.afterstates(include_terminal=True)
+        want_all = fit(rfa)
+        got = fa.cpu().numpy()
+        for i in range(B):
+            np.testing.assert_array_equal(got[i, :rna[i]], want_all[i, :rna[i]])
+            if rnv[i]:
+                v = fit(rf[i, :rnv[i]])
+                assert int(ba[i]) == int(np.argmax(v)) and float(bv[i]) == float(v.max())
+            else:
+                assert int(ba[i]) == -1
+        # play the greedy action (random where none exists: those envs are done anyway)
+        act = torch.where(ba >= 0, ba, torch.zeros_like(ba))
+        env.step(act)
+        ref.step(act.cpu().numpy())
+    # recorded reference policies
+    g = np.load(os.path.join(golden_dir, "g6_policy.npz"))
+    for tag, pieces in (("default_20", "default"), ("standard7_20", STANDARD7)):
+        boards, plist = g[tag + "_boards"], g[tag + "_pieces"]
+        n = len(boards)
+        e2 = VecTetris(10, 20, n, device=device, pieces=pieces)
+        e2.set_boards(orc.cols_to_cells(boards, 24), piece=plist.astype(np.int64))
+        _, _, fa = e2.greedy_actions(include_fitness=True)
+        fa = fa.cpu().numpy()
+        for t in range(n):
+            pol_ref = g[tag + "_policy"][t]
+            na = int((pol_ref > 0).nonzero()[0].max()) + 1 if pol_ref.any() else 0
+            k = len(np.trim_zeros(g[tag + "_fitness"][t], "b"))
+            k = max(k, na)
+            f = fa[t, :k]
+            pol = (f == f.max()).astype(float)
+            pol /= pol.sum()
+            np.testing.assert_array_equal(pol, pol_ref[:k])
+            np.testing.assert_array_equal(f, g[tag + "_fitness"][t][:k].astype(np.float32))

@@ -59,3 +59,15 @@ def test_facade_golden_trajectories(golden_dir):
     fc.reset_features(DEV, golden_dir)
     fc.best_policy(DEV, golden_dir)
     fc.rollouts_and_misc(DEV)
+
+
+def test_edge_geometries(orc):
+    pc.edge_geometries(DEV, orc)
+
+
+def test_step_without_obs(orc):
+    pc.step_without_obs(DEV, orc)
+
+
+def test_greedy_policy(orc, golden_dir):
+    pc.greedy_policy(DEV, orc, golden_dir)

@@ -39,3 +39,15 @@ def test_mask_rescue_stress(host_backend, orc):
     pc.mask_rescue_stress(DEV, orc, n_boards=600)
     pc.mask_rescue_stress(DEV, orc, n_boards=200, R=40, seed=1)
     pc.mask_rescue_stress(DEV, orc, n_boards=200, R=10, C=6, seed=2)
+
+
+def test_edge_geometries(host_backend, orc):
+    pc.edge_geometries(DEV, orc)
+
+
+def test_step_without_obs(host_backend, orc):
+    pc.step_without_obs(DEV, orc)
+
+
+def test_greedy_policy(host_backend, orc, golden_dir):
+    pc.greedy_policy(DEV, orc, golden_dir)

@@ -40,6 +40,16 @@
 #define TET_SCRATCH_OR(ptr, v) (*(ptr) |= (v))
 #endif
 
+// float32 multiply / add that the compiler may not contract into an FMA (the reference's
+// fitness sum rounds every product and every partial sum, game.py:109-118)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define TET_FMUL(a, b) __fmul_rn((a), (b))
+#define TET_FADD(a, b) __fadd_rn((a), (b))
+#else
+#define TET_FMUL(a, b) ((float)((volatile float)(a) * (b)))
+#define TET_FADD(a, b) ((float)((volatile float)(a) + (b)))
+#endif
+
 namespace tet {
 
 constexpr int kMaxPieces = 12;   // pieces in one set (bag is 12 bits of meta)
@@ -698,6 +708,16 @@ TET_HD void afterstates_env(const W (&col)[C], uint64_t meta, const SetTable& ta
   }
 }
 
+// Tetris.fitness (game.py:107-120): linear evaluation of one feature vector, left to right,
+// in float32 (NumPy >= 2 keeps float32 * python-float in float32; the golden vectors were
+// recorded that way).
+TET_HD float fitness_of(const float (&f)[8], const float (&w)[8]) {
+  float acc = TET_FMUL(f[0], w[0]);
+#pragma unroll
+  for (int q = 1; q < 8; ++q) acc = TET_FADD(acc, TET_FMUL(f[q], w[q]));
+  return acc;
+}
+
 // ---- one env step (game.py:82-92) --------------------------------------------
 struct StepOut {
   float obs[8];
@@ -716,6 +736,7 @@ struct StepCfg {
   int auto_reset;
   uint32_t key_step;    // hash_key(seed, 4*step_idx + 0): piece draws of this step
   uint32_t key_policy;  // hash_key(seed, 4*step_idx + 3): built-in uniform random policy
+  int compute_obs;      // 0: the caller passed obs = NULL (it already holds the afterstate features)
   float direct_by[8];   // state.py:49-50
   int has_direct_by;
 };
@@ -761,7 +782,7 @@ TET_HD void env_step(W (&col)[C], uint64_t& meta, int action, bool use_policy, c
   int eroded = 0;
   const int k = (TET_ABLATE & 8) ? 0 : clear_lines<W, C>(col, pbits, &eroded);   // state.py:33
   heights_of<W, C>(col, h);
-  if (TET_ABLATE & 1) {
+  if ((TET_ABLATE & 1) || !cfg.compute_obs) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) out.obs[i] = (float)h[i];
   } else

@@ -145,9 +145,11 @@ __global__ __launch_bounds__(kBlock, TET_STEP_WAVES) void step_kernel(const Step
     tet::env_step<W, C>(in.col, in.meta, in.action, p.action == nullptr, tab, hole_lut, &lane_cols[0][threadIdx.x],
                         kBlock, p.cfg, p.env_offset + i, in.draw, in.draw_reset, out);
     invalid = out.invalid;
-    float4* o4 = reinterpret_cast<float4*>(p.obs) + 2 * i;
-    o4[0] = make_float4(out.obs[0], out.obs[1], out.obs[2], out.obs[3]);
-    o4[1] = make_float4(out.obs[4], out.obs[5], out.obs[6], out.obs[7]);
+    if (p.obs) {
+      float4* o4 = reinterpret_cast<float4*>(p.obs) + 2 * i;
+      o4[0] = make_float4(out.obs[0], out.obs[1], out.obs[2], out.obs[3]);
+      o4[1] = make_float4(out.obs[4], out.obs[5], out.obs[6], out.obs[7]);
+    }
     if (!invalid) {
 #pragma unroll
       for (int c = 0; c < C; ++c) cols[(uint32_t)c * p.B + i] = in.col[c];
@@ -337,6 +339,58 @@ __global__ __launch_bounds__(kBlock, TET_AFTER_WAVES) void afterstates_kernel(co
   if (p.n_all) p.n_all[i] = (uint8_t)na;
 }
 
+struct GreedyParams {
+  const void* cols;
+  const uint64_t* meta;
+  int32_t* best_action;
+  float* best_value;
+  float* fitness_all;
+  int64_t B;
+  int32_t R;
+  int32_t a_max;
+  float w[8];
+  SetTable tab;
+};
+
+// Tetris.get_best_policy / fitness (game.py:102-120) for every env: the fitness of every
+// placement (raw order, terminal included, like game.py:103) and the best NON-terminal action.
+// The [B][a_max][8] feature matrix never touches HBM.
+template <typename W, int C>
+__global__ __launch_bounds__(kBlock) void greedy_kernel(const GreedyParams p) {
+  __shared__ SetTable tab;
+  __shared__ __attribute__((aligned(16))) uint8_t hole_lut[tet::kHoleLutSize];
+  stage_hole_lut(hole_lut);
+  stage_table(tab, p.tab);
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= p.B) return;
+  const W* cols = static_cast<const W*>(p.cols);
+  W col[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) col[c] = cols[(int64_t)c * p.B + i];
+  const uint64_t meta = p.meta[i];
+  const int piece = tet::meta_piece(meta);
+  const uint64_t full = tab.fullmask[piece];
+  const uint64_t valid = tet::meta_mask(meta) & full;
+  float* fall = p.fitness_all ? p.fitness_all + i * (int64_t)p.a_max : nullptr;
+  float best = 0.f;
+  int best_row = -1;
+  tet::afterstates_env<W, C>(col, meta, tab, hole_lut, p.R, [&](int s, float (&f)[8]) {
+    const float v = tet::fitness_of(f, p.w);
+    if (fall) fall[tet::row_of_slot(full, s)] = v;
+    if ((valid >> s) & 1) {
+      const int row = tet::row_of_slot(valid, s);
+      if (best_row < 0 || v > best || (v == best && row < best_row)) {
+        best = v;
+        best_row = row;
+      }
+    }
+  });
+  if (fall)
+    for (int k = tet::popc(full); k < p.a_max; ++k) fall[k] = 0.f;
+  p.best_action[i] = best_row;
+  if (p.best_value) p.best_value[i] = best;
+}
+
 __global__ __launch_bounds__(kBlock) void policy_random_kernel(const uint8_t* __restrict__ n_valid,
                                                                int32_t* __restrict__ action, uint32_t key,
                                                                int64_t env_offset, int64_t B) {
@@ -406,6 +460,12 @@ template <typename W, int C>
 struct LaunchRefresh {
   static void run(const RefreshParams& p, hipStream_t s) {
     hipLaunchKernelGGL((refresh_kernel<W, C>), grid_for(p.B), dim3(kBlock), 0, s, p);
+  }
+};
+template <typename W, int C>
+struct LaunchGreedy {
+  static void run(const GreedyParams& p, hipStream_t s) {
+    hipLaunchKernelGGL((greedy_kernel<W, C>), grid_for(p.B), dim3(kBlock), 0, s, p);
   }
 };
 template <typename W, int C>
@@ -494,7 +554,7 @@ int tetris_hip_step(const TetrisDesc* desc, void* cols, uint64_t* meta, const in
                     void* hip_stream) {
   int rc = check_desc(desc);
   if (rc) return rc;
-  if (!cols || !meta || !obs || !reward || !done || !lines || !n_valid_next) return TETRIS_E_NULL;
+  if (!cols || !meta || !reward || !done || !lines || !n_valid_next) return TETRIS_E_NULL;
   if (B <= 0 || B > 0x7FFFFFFF / (desc->num_columns * desc->word_bytes)) return TETRIS_E_BATCH;
   if (stream && (!cursor || stream_len <= 0)) return TETRIS_E_STREAM;
   StepParams p;
@@ -519,6 +579,7 @@ int tetris_hip_step(const TetrisDesc* desc, void* cols, uint64_t* meta, const in
   p.cfg.auto_reset = auto_reset;
   p.cfg.key_step = tet::hash_key(seed, step_idx * 4u + 0u);
   p.cfg.key_policy = tet::hash_key(seed, step_idx * 4u + 3u);
+  p.cfg.compute_obs = obs != nullptr;
   p.cfg.has_direct_by = desc->has_direct_by;
   for (int i = 0; i < 8; ++i) p.cfg.direct_by[i] = desc->direct_by[i];
   build_table(desc, &p.tab);
@@ -549,6 +610,27 @@ int tetris_hip_afterstates(const TetrisDesc* desc, const void* cols, const uint6
   for (int i = 0; i < 8; ++i) p.direct_by[i] = desc->direct_by[i];
   build_table(desc, &p.tab);
   return dispatch<LaunchAfter>(desc, p, (hipStream_t)hip_stream);
+}
+
+int tetris_hip_policy_greedy(const TetrisDesc* desc, const void* cols, const uint64_t* meta, const float* weights,
+                             int32_t* best_action, float* best_value, float* fitness_all, int64_t B,
+                             void* hip_stream) {
+  int rc = check_desc(desc);
+  if (rc) return rc;
+  if (!cols || !meta || !weights || !best_action) return TETRIS_E_NULL;
+  if (B <= 0) return TETRIS_E_BATCH;
+  GreedyParams p;
+  p.cols = cols;
+  p.meta = meta;
+  p.best_action = best_action;
+  p.best_value = best_value;
+  p.fitness_all = fitness_all;
+  p.B = B;
+  p.R = desc->num_rows;
+  p.a_max = desc->a_max;
+  for (int i = 0; i < 8; ++i) p.w[i] = weights[i];
+  build_table(desc, &p.tab);
+  return dispatch<LaunchGreedy>(desc, p, (hipStream_t)hip_stream);
 }
 
 int tetris_hip_refresh(const TetrisDesc* desc, const void* cols, uint64_t* meta, uint8_t* n_valid_out,

@@ -34,6 +34,8 @@ class VecTetris:
                  device bag (parity runs against a recorded NumPy stream)
     env_offset   global index of env 0 (shards of one logical batch draw the
                  same pieces as the unsharded batch)
+    compute_obs  False: step() skips the BCTS observation (obs stays zero); for agents that
+                 already hold get_after_states() features, whose row `action` is that observation
     afterstate_layout  storage of the get_after_states matrices: "env_major" (contiguous
                  [B, a_max, 8], default, fastest on MI355X) or "action_major"
                  ([a_max, B, 8] storage returned as a [B, a_max, 8] view)
@@ -43,7 +45,8 @@ class VecTetris:
     """
 
     def __init__(self, num_columns, num_rows, batch_size, device="cuda", pieces="default", auto_reset=False,
-                 seed=0, feature_directions=None, piece_stream=None, env_offset=0, afterstate_layout="env_major"):
+                 seed=0, feature_directions=None, piece_stream=None, env_offset=0, afterstate_layout="env_major",
+                 compute_obs=True):
         self._lib = _lib.load()
         self.device = torch.device(device)
         if self.device.type != self._lib.device_type:
@@ -61,6 +64,7 @@ class VecTetris:
         if afterstate_layout not in ("action_major", "env_major"):
             raise ValueError("afterstate_layout must be 'action_major' or 'env_major'")
         self.afterstate_layout = afterstate_layout
+        self.compute_obs = bool(compute_obs)
         self.loss_reward, self.timestep_reward = -100, -1  # game.py:34-35 (baked into the kernel)
 
         ids = (ctypes.c_int32 * len(self.piece_names))(*[CATALOGUE.index(n) for n in self.piece_names])
@@ -181,12 +185,39 @@ class VecTetris:
         s, c, n = self._stream_args()
         rc = self._lib.step(ctypes.byref(self.desc), _ptr(self.cols), _ptr(self.meta), _ptr(a),
                             _ptr(self.action) if a is None else None, s, c, n,
-                            _ptr(self.obs), _ptr(self.reward), _ptr(self._done), _ptr(self.lines), _ptr(self.n_valid),
+                            _ptr(self.obs) if self.compute_obs else None, _ptr(self.reward), _ptr(self._done), _ptr(self.lines), _ptr(self.n_valid),
                             _ptr(self.piece), _ptr(self.status), int(self.auto_reset), self.seed, self.step_idx,
                             self.env_offset, self.batch_size, self._hip_stream())
         self._lib.check(rc, "tetris_hip_step")
         self.step_idx += 1
         return self.obs, self.reward, self.done, self.lines
+
+    BCTS_WEIGHTS = (-24.04, -19.77, -13.08, -12.63, -10.49, -9.22, 6.6, -1.61)  # game.py:111-118
+
+    def greedy_actions(self, weights=None, include_fitness=False):
+        """Tetris.get_best_policy / fitness (game.py:102-120) for every env, without materialising
+        the feature matrix: returns ``(best_action int32 [B], best_value float32 [B])`` -- the first
+        non-terminal action of maximal linear fitness (-1 when the env has none) -- and with
+        ``include_fitness`` also ``fitness_all float32 [B, a_max]`` over ALL placements in raw order
+        (terminal included, the domain of the reference's policy vector)."""
+        w = (ctypes.c_float * 8)(*(self.BCTS_WEIGHTS if weights is None else [float(x) for x in weights]))
+        B = self.batch_size
+        if not hasattr(self, "_best_action"):
+            self._best_action = torch.empty(B, dtype=torch.int32, device=self.device)
+            self._best_value = torch.empty(B, dtype=torch.float32, device=self.device)
+            self._fitness_all = None
+        fa = None
+        if include_fitness:
+            if self._fitness_all is None:
+                self._fitness_all = torch.empty((B, self.a_max), dtype=torch.float32, device=self.device)
+            fa = self._fitness_all
+        rc = self._lib.policy_greedy(ctypes.byref(self.desc), _ptr(self.cols), _ptr(self.meta), w,
+                                     _ptr(self._best_action), _ptr(self._best_value), _ptr(fa), B,
+                                     self._hip_stream())
+        self._lib.check(rc, "tetris_hip_policy_greedy")
+        if include_fitness:
+            return self._best_action, self._best_value, fa
+        return self._best_action, self._best_value
 
     def random_actions(self, out=None):
         """Uniform random valid action per env (the random-rollout policy)."""
