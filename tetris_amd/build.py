@@ -28,7 +28,7 @@ def build_hip(force=False, verbose=False):
     """Compile the HIP kernels + C-ABI for gfx950 into tetris_amd/csrc/libtetris_hip.so."""
     if not force and not is_stale():
         return SO_PATH
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC",
            os.path.join(_CSRC, "tetris_kernels.hip"), "-o", SO_PATH]
     if verbose:
         print(" ".join(cmd))

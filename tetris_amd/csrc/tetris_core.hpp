@@ -712,6 +712,9 @@ TET_HD void afterstates_env(const W (&col)[C], uint64_t meta, const SetTable& ta
 // in float32 (NumPy >= 2 keeps float32 * python-float in float32; the golden vectors were
 // recorded that way).
 TET_HD float fitness_of(const float (&f)[8], const float (&w)[8]) {
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
   float acc = TET_FMUL(f[0], w[0]);
 #pragma unroll
   for (int q = 1; q < 8; ++q) acc = TET_FADD(acc, TET_FMUL(f[q], w[q]));

@@ -22,7 +22,7 @@ for t in range(150):
 abl = int(os.environ.get("ABL_MASK", "0"))
 if abl:
     out = "/tmp/libtetris_abl_%d.so" % abl
-    subprocess.check_call([build._hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
+    subprocess.check_call([build._hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC",
                            "-DTET_ABLATE=%d" % abl, os.path.join(ROOT, "tetris_amd", "csrc", "tetris_kernels.hip"),
                            "-o", out])
     env._lib = _lib._Binding(ctypes.CDLL(out))
