@@ -71,3 +71,33 @@ def test_step_without_obs(orc):
 
 def test_greedy_policy(orc, golden_dir):
     pc.greedy_policy(DEV, orc, golden_dir)
+
+
+def test_integration_md_stub_runs():
+    """The ctypes stub printed in INTEGRATION.md is executable as written and agrees with VecTetris."""
+    import os
+    import re
+    import torch
+    from tetris_amd import VecTetris, build
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    code = re.search(r"```python\n(.*?)```", text, re.S).group(1)
+    code = code.replace('ctypes.CDLL("libtetris_hip.so")', 'ctypes.CDLL(%r)' % build.SO_PATH)
+    ns = {}
+    exec(compile(code, "INTEGRATION.md", "exec"), ns)
+    ThreeL = type("ThreeL", (), {})
+    ThreeLine = type("ThreeLine", (), {})
+    ref_env = type("Env", (), dict(num_columns=10, num_rows=20, tetrominos=[ThreeL(), ThreeLine()]))()
+    B = 1000
+    hb = ns["HipBoards"](ref_env, B)
+    hb.reset(seed=5)
+    env = VecTetris(10, 20, B, device="cuda", auto_reset=True, seed=5)
+    assert torch.equal(hb.meta, env.meta)
+    for t in range(30):
+        feats, nv = hb.get_after_states()
+        f2, nv2 = env.get_after_states()
+        assert torch.equal(feats, f2) and torch.equal(nv, nv2)
+        a = env.random_actions().clone()
+        hb.step(a, seed=5)
+        env.step(a)
+        assert torch.equal(hb.cols, env.cols) and torch.equal(hb.obs, env.obs) and torch.equal(hb.meta, env.meta)
