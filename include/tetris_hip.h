@@ -24,10 +24,10 @@
  *          (game.py:56, state.py:27-30).  Word = uint32 if R+4 <= 31,
  *          uint64 if R+4 <= 63 (TetrisDesc.word_bytes).
  *  meta  : uint64[B] per-env control word:
- *            bits  0-47 valid mask over static slots s = 4c + 2L + o (column c,
- *                       loop L, orientation o of tetromino.py's enumeration);
- *                       action k (game.py:69,83) is the k-th set bit of the
- *                       L = 0 slots followed by the L = 1 slots
+ *            bits  0-47 valid mask: four C-bit fields, field 2L + o (loop L,
+ *                       orientation o of tetromino.py's enumeration), bit c = left
+ *                       column c; action k (game.py:69,83) counts the set bits of
+ *                       fields 0,1 interleaved by column, then of fields 2,3
  *            bits 48-51 current piece (index into the piece list, game.py:38-39)
  *            bits 52-63 bag: list indices still to be drawn (tetromino.py:12-22)
  */

@@ -149,14 +149,15 @@ void after_impl(const TetrisDesc* desc, const void* cols_, const uint64_t* meta,
     }
     int nv = tet::popc(valid), na = tet::popc(full);
     bool consistent = true;
-    tet::afterstates_env<W, C>(col, meta[i], tab, kHoleLut, R, [&](int s, float (&f)[8]) {
+    tet::afterstates_env<W, C>(col, meta[i], tab, kHoleLut, R, [&](int sk, int sc, float (&f)[8]) {
+      const int s = C * sk + sc;
       // cross-checks (test harness only): (1) the incremental features against the full
       // evaluation of the same placement, (2) the cached mask against the direct terminal test
-      const tet::Orient o = tet::unpack_orient(tab.orient[piece][s & 3][0]);
+      const tet::Orient o = tet::unpack_orient(tab.orient[piece][sk][0]);
       W nb[C];
       W pbits[4];
       int nh[C];
-      const int a = tet::stamp_static<W, C>(col, h, s >> 2, o, nb, pbits);
+      const int a = tet::stamp_static<W, C>(col, h, sc, o, nb, pbits);
       int eroded = 0;
       const int k = tet::clear_lines<W, C>(nb, pbits, &eroded);
       tet::heights_of<W, C>(nb, nh);
@@ -167,8 +168,8 @@ void after_impl(const TetrisDesc* desc, const void* cols_, const uint64_t* meta,
       consistent = consistent && (terminal != (bool)((valid >> s) & 1));
       if (desc->has_direct_by)
         for (int q = 0; q < 8; ++q) f[q] *= desc->direct_by[q];
-      if (out_all) memcpy(out_all + tet::row_of_slot(full, s) * rs, f, sizeof(float) * 8);
-      if ((valid >> s) & 1) memcpy(out_valid + tet::row_of_slot(valid, s) * rs, f, sizeof(float) * 8);
+      if (out_all) memcpy(out_all + tet::row_of_slot<C>(full, sk, sc) * rs, f, sizeof(float) * 8);
+      if ((valid >> s) & 1) memcpy(out_valid + tet::row_of_slot<C>(valid, sk, sc) * rs, f, sizeof(float) * 8);
     });
     if (!consistent) nv = 255;  // fail loudly in the tests
     n_valid[i] = (uint8_t)nv;
@@ -276,11 +277,11 @@ int tetris_host_policy_greedy(const TetrisDesc* desc, const void* cols_, const u
         for (int k = 0; k < desc->a_max; ++k) fall[k] = 0.f;
       float best = 0.f;
       int best_row = -1;
-      tet::afterstates_env<W, C>(col, meta[i], tab, kHoleLut, desc->num_rows, [&](int s, float (&f)[8]) {
+      tet::afterstates_env<W, C>(col, meta[i], tab, kHoleLut, desc->num_rows, [&](int sk, int sc, float (&f)[8]) {
         const float v = tet::fitness_of(f, w);
-        if (fall) fall[tet::row_of_slot(full, s)] = v;
-        if ((valid >> s) & 1) {
-          const int row = tet::row_of_slot(valid, s);
+        if (fall) fall[tet::row_of_slot<C>(full, sk, sc)] = v;
+        if ((valid >> (C * sk + sc)) & 1) {
+          const int row = tet::row_of_slot<C>(valid, sk, sc);
           if (best_row < 0 || v > best || (v == best && row < best_row)) {
             best = v;
             best_row = row;

@@ -80,10 +80,10 @@ TET_HD Orient unpack_orient(uint32_t d) {
 }
 
 // ---- meta word ------------------------------------------------------------
-// bits 0-47  valid mask over static slots s = 4c + 2L + o.  The reference
-//            enumerates (loop L, column c, orientation o) in that order, so
-//            action k is the k-th set bit of the L = 0 slots followed by the
-//            L = 1 slots, each taken in ascending bit order (slot_of_action)
+// bits 0-47  valid mask: four C-bit fields, field k = 2L + o (loop L, orientation o of
+//            tetromino.py's enumeration), bit c of a field = left column c.  The reference
+//            enumerates (L, c, o) in that order, so action k walks fields 0 and 1 interleaved
+//            by column, then fields 2 and 3 (slot_of_action)
 // bits 48-51 current piece (list index, game.py:38-39)
 // bits 52-63 bag: list indices still to be drawn (tetromino.py:12-22)
 constexpr uint64_t kMaskBits = (1ull << 48) - 1;
@@ -175,35 +175,54 @@ TET_HD int bag_draw(uint32_t& bag, int n_pieces, uint32_t r16) {
 
 // ---- per-set table staged in LDS -------------------------------------------
 // orient[p][L*2+o][0]  packed Orient descriptor (above)
-//                  [1]  threshold shifts into the blocked-thermometer word (valid_mask):
-//                       bits 0-15  four 4-bit shifts for the real thresholds,
-//                       bits 16-31 four 4-bit shifts for the thresholds relaxed by one row
-//                  [2]  rescue rows (valid_mask): for t in {1,2} (board rows R-3+t) at
-//                       5t-5: has | j0<<1 | j1<<3; bit 10 vertical Straight; bit 11 relaxed
+//                  [1]  valid_mask: four 6-bit shifts into the level word for the real
+//                       thresholds (bits 0-23); bit 24 vertical Straight; bit 25 relaxed
 //                       thresholds unconstrained
+//                  [2]  valid_mask: four 6-bit shifts for the thresholds relaxed by one row
+//                  [3]  valid_mask rescue rows: for t in {1,2} (board rows R-3+t) at 5t-5:
+//                       has | j0<<1 | j1<<3
 struct SetTable {
-  uint32_t orient[kMaxPieces][4][3];
-  uint64_t fullmask[kMaxPieces];   // all existing slots (every placement valid)
+  uint32_t orient[kMaxPieces][4][4];
+  uint64_t fullmask[kMaxPieces];   // all existing placements (every one valid)
 };
 
 // hole-depth table (tools/gen_hole_lut.py): 8 KiB, staged in LDS by the kernels
 constexpr int kHoleLutSize = 1 << 13;
 
-constexpr uint64_t kLoop0Slots = 0x3333333333333333ull;  // slots with L = 0
-
-// action k -> slot, given the valid mask (game.py:69,83: index into the non-terminal
-// placements in enumeration order)
-TET_HD int slot_of_action(uint64_t mask, int k) {
-  const uint64_t m0 = mask & kLoop0Slots;
-  const int n0 = popc(m0);
-  const bool second = k >= n0;
-  return select_bit(second ? (mask & ~kLoop0Slots) : m0, second ? k - n0 : k);
+// bit c -> bit 2c (c < 16)
+TET_HD uint32_t spread2(uint32_t x) {
+  x = (x | (x << 8)) & 0x00FF00FFu;
+  x = (x | (x << 4)) & 0x0F0F0F0Fu;
+  x = (x | (x << 2)) & 0x33333333u;
+  x = (x | (x << 1)) & 0x55555555u;
+  return x;
 }
-// row of slot s in the list of valid (or of all) placements
-TET_HD int row_of_slot(uint64_t mask, int s) {
-  const uint64_t below = (1ull << s) - 1;
-  const uint64_t m0 = mask & kLoop0Slots, m1 = mask & ~kLoop0Slots;
-  return ((s >> 1) & 1) ? popc(m0) + popc(m1 & below) : popc(m0 & below);
+
+template <int C>
+TET_HD uint32_t mask_field(uint64_t mask, int k) { return (uint32_t)(mask >> (C * k)) & ((1u << C) - 1u); }
+
+// action k -> (field kk = 2L + o, column c), given the valid mask (game.py:69,83: index into
+// the non-terminal placements in enumeration order loop, column, orientation)
+template <int C>
+TET_HD void slot_of_action(uint64_t mask, int k, int& kk, int& c) {
+  const uint32_t f0 = mask_field<C>(mask, 0), f1 = mask_field<C>(mask, 1);
+  const uint32_t f2 = mask_field<C>(mask, 2), f3 = mask_field<C>(mask, 3);
+  const int n0 = popc(f0) + popc(f1);
+  const bool second = k >= n0;
+  const uint32_t z = spread2(second ? f2 : f0) | (spread2(second ? f3 : f1) << 1);  // (c, o) order
+  const int pos = select_bit32(z, second ? k - n0 : k);
+  c = pos >> 1;
+  kk = (second ? 2 : 0) + (pos & 1);
+}
+// row of placement (kk, c) in the list of the placements whose bits are set in `mask`
+template <int C>
+TET_HD int row_of_slot(uint64_t mask, int kk, int c) {
+  const int L = kk >> 1;
+  const uint32_t fa = mask_field<C>(mask, 2 * L), fb = mask_field<C>(mask, 2 * L + 1);
+  const uint32_t below = (1u << c) - 1u;
+  int row = popc(fa & below) + popc(fb & below) + ((kk & 1) ? (int)((fa >> c) & 1u) : 0);
+  if (L) row += popc(mask_field<C>(mask, 0)) + popc(mask_field<C>(mask, 1));
+  return row;
 }
 
 template <typename W, int C>
@@ -387,11 +406,11 @@ TET_HD void bcts_features(const W (&col)[C], const int (&h)[C], int R, const uin
 // (state.py:33,36,111-117).  The piece spans rows a..a+H-1 with a cell in every
 // one of them and every cleared row lies inside that span, so
 //      terminal  <=>  e := a + H - R  >  n_cleared.
-// All columns c of one orientation are evaluated at once on small bit-fields:
+// All columns c of one orientation are evaluated at once on C-bit column sets:
 //  * slack s_c = R - h_c; footprint column j needs s_{c+j} >= need_j = H - b_j.
-//    X holds per column the 4-bit "blocked thermometer" [s<1, s<2, s<3, s<4];
-//    OR_j (X >> (need_j-1 + 4j)) has bit 4c set iff e >= 1 at column c (I1);
-//    the same with need_j-1 gives e >= 2 (I2).
+//    B_l = {c : s_c < l} for l = 1..4 (built with byte-parallel compares of the packed
+//    heights); OR_j (B_{need_j} >> j) = columns where the placement pokes >= 1 row above
+//    R-1 (I1); the same with need_j - 1 gives "pokes >= 2 rows" (I2).
 //  * e = 1 (I1 & ~I2): the anchor is exactly a = R+1-H, so the piece's row rho sits
 //    in board row R-3+t, t = rho+4-H.  That row becomes full iff all its missing
 //    columns lie inside the piece's (contiguous) run [c+j0, c+j1] of that row, i.e.
@@ -401,20 +420,28 @@ TET_HD void bcts_features(const W (&col)[C], const int (&h)[C], int R, const uin
 //  * e >= 2 can only be rescued when H = 4 (vertical Straight): rows R-2 and R-1 must
 //    both miss exactly column c.
 template <typename W, int C>
-TET_HD uint64_t valid_mask(const W (&col)[C], const int (&h)[C], const uint32_t (&tab)[4][3],
+TET_HD uint64_t valid_mask(const W (&col)[C], const int (&h)[C], const uint32_t (&tab)[4][4],
                            uint64_t fullmask, int R) {
   static_assert(C <= 10, "missing-cell rows are packed 3 bits per column into 32 bits");
-  uint32_t Xlo = 0, Xhi = 0, Fall = 0;
+  uint32_t P[3] = {0u, 0u, 0u};
+  uint32_t Fall = 0;
 #pragma unroll
   for (int c = 0; c < C; ++c) {
-    int sl = R - h[c];
-    sl = sl < 4 ? sl : 4;
-    sl = sl > 0 ? sl : 0;
-    const uint32_t th = (0xFu << sl) & 0xFu;  // [s<1, s<2, s<3, s<4]
-    if (c < 8) Xlo |= th << (4 * c);
-    else Xhi |= th << (4 * (c - 8));
+    P[c >> 2] |= (uint32_t)h[c] << (8 * (c & 3));
     Fall |= ((uint32_t)(col[c] >> (R - 3)) & 7u) << (3 * c);  // cells of rows R-3..R-1
   }
+  uint32_t lv[4];
+#pragma unroll
+  for (int l = 1; l <= 4; ++l) {
+    // byte b of P + K has bit 7 set iff h_b > R - l  (h <= 63, K <= 127: no carry between bytes)
+    const uint32_t K = (uint32_t)(127 - (R - l)) * 0x01010101u;
+    uint32_t g = 0;
+#pragma unroll
+    for (int q = 0; q < (C + 3) / 4; ++q)
+      g |= ((((P[q] + K) & 0x80808080u) * 0x00204081u) >> 28) << (4 * q);  // gather the four bit-7s
+    lv[l - 1] = g;
+  }
+  const uint64_t BB = (uint64_t)(lv[0] | (lv[1] << 16)) | ((uint64_t)(lv[2] | (lv[3] << 16)) << 32);
   const uint32_t Mall = ~Fall;  // missing cells, 3 bits per column
   int lo[3], hi[3];
   uint32_t single[3];
@@ -426,25 +453,18 @@ TET_HD uint64_t valid_mask(const W (&col)[C], const int (&h)[C], const uint32_t 
     hi[t] = m ? ((31 - __builtin_clz(m)) * 11) >> 5 : 31;
     single[t] = (lo[t] == hi[t]) ? (1u << lo[t]) : 0u;
   }
-  // vertical Straight rescued by two cleared rows: rows R-2 and R-1 both miss exactly column cc
-  const bool two = (single[1] & single[2]) != 0;
-  const uint32_t r2lo = (two && lo[1] < 8) ? (1u << (4 * lo[1])) : 0u;
-  const uint32_t r2hi = (two && lo[1] >= 8) ? (1u << (4 * (lo[1] - 8))) : 0u;
-  uint32_t mlo = 0, mhi = 0;
+  const uint32_t cm = (1u << C) - 1u;
+  uint64_t mask = 0;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    const uint32_t shw = tab[k][1], rw = tab[k][2];
-    uint32_t i1lo = 0, i1hi = 0, i2lo = 0, i2hi = 0;
+    const uint32_t w1 = tab[k][1], w2 = tab[k][2], rw = tab[k][3];
+    uint32_t i1 = 0, i2 = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const uint32_t s1 = (shw >> (4 * j)) & 15u, s2 = (shw >> (16 + 4 * j)) & 15u;
-      const uint64_t X = ((uint64_t)Xhi << 32) | Xlo;
-      i1lo |= (uint32_t)(X >> s1);
-      i1hi |= Xhi >> s1;
-      i2lo |= (uint32_t)(X >> s2);
-      i2hi |= Xhi >> s2;
+      i1 |= (uint32_t)(BB >> ((w1 >> (6 * j)) & 63u));
+      i2 |= (uint32_t)(BB >> ((w2 >> (6 * j)) & 63u));
     }
-    if ((rw >> 11) & 1u) { i2lo = 0; i2hi = 0; }
+    if ((w1 >> 25) & 1u) i2 = 0;
     // rescue by one cleared row (e = 1)
     uint32_t r1 = 0;
 #pragma unroll
@@ -459,21 +479,15 @@ TET_HD uint64_t valid_mask(const W (&col)[C], const int (&h)[C], const uint32_t 
       const uint32_t iv = ((1u << len) - 1u) << c0;
       r1 |= (f & 1u) ? iv : 0u;
     }
-    const bool vert4 = (rw >> 10) & 1u;  // vertical Straight: any of its three lower rows
-    if (vert4) r1 = single[0] | single[1] | single[2];
-    const uint32_t b0 = vert4 ? r2lo : 0u, b1 = vert4 ? r2hi : 0u;
-    // spread bit c -> bit 4c
-    uint32_t a0 = r1 & 0xFFu;
-    a0 = (a0 | (a0 << 12)) & 0x000F000Fu;
-    a0 = (a0 | (a0 << 6)) & 0x03030303u;
-    a0 = (a0 | (a0 << 3)) & 0x11111111u;
-    const uint32_t a1 = ((r1 >> 8) & 1u) | (((r1 >> 9) & 1u) << 4);
-    const uint32_t vlo = (~i1lo | (~(i2lo & ~b0) & a0)) & 0x11111111u;
-    const uint32_t vhi = (~i1hi | (~(i2hi & ~b1) & a1)) & 0x11111111u;
-    mlo |= vlo << k;  // slot 4c + 2L + o with k = 2L + o
-    mhi |= vhi << k;
+    uint32_t r2 = 0;
+    if ((w1 >> 24) & 1u) {  // vertical Straight: any of its three lower rows / both of R-2, R-1
+      r1 = single[0] | single[1] | single[2];
+      r2 = single[1] & single[2];
+    }
+    const uint32_t v = (~i1 | (~(i2 & ~r2) & r1)) & cm;
+    mask |= (uint64_t)v << (C * k);
   }
-  return ((((uint64_t)mhi << 32) | mlo) & fullmask);
+  return mask & fullmask;
 }
 
 // ---- the chosen placement (left column only known at run time) --------------
@@ -547,7 +561,7 @@ TET_HD int stamp_scratch(W (&col)[C], W* scratch, int sstride, int c, uint32_t d
 }
 
 // ---- all afterstates of one env (game.py:67-80) -----------------------------------------
-// emit(slot, f[8]) is called for every existing placement of the current piece with the BCTS
+// emit(field k = 2L + o, column c, f[8]) is called for every existing placement of the current piece with the BCTS
 // features of its afterstate.  The per-column feature terms of the current board are computed
 // once; a placement that clears no line changes at most its footprint columns, so only those
 // (plus the wells of the left neighbour and the row transitions / wells of the right one) are
@@ -596,7 +610,7 @@ TET_HD void afterstates_env(const W (&col)[C], uint64_t meta, const SetTable& ta
     const bool u1 = TET_WAVE_ANY(o.w > 1), u2 = TET_WAVE_ANY(o.w > 2), u3 = TET_WAVE_ANY(o.w > 3);
 #pragma unroll
     for (int c = 0; c < C; ++c) {
-      const int s = 4 * c + k;
+      const int s = C * k + c;
       if (!((full >> s) & 1)) continue;
       int a = 0;
 #pragma unroll
@@ -686,7 +700,7 @@ TET_HD void afterstates_env(const W (&col)[C], uint64_t meta, const SetTable& ta
       f[5] = (float)(R - pl + (int)(dA >> 20));
       f[6] = 0.0f;
       f[7] = (float)(dB >> 16);
-      emit(s, f);
+      emit(k, c, f);
     }
   }
   while (slow != 0) {  // line-clearing placements (rare): full evaluation, state.py:33 onwards
@@ -697,14 +711,15 @@ TET_HD void afterstates_env(const W (&col)[C], uint64_t meta, const SetTable& ta
     for (int i = 0; i < C; ++i) fb[i] = col[i];
     W pbits[4];
     int fh[C];
-    const uint32_t od = tab.orient[piece][s & 3][0];
-    const int aa = stamp_dynamic<W, C>(fb, h, s >> 2, od, pbits);
+    const int sk = s / C, sc = s - sk * C;
+    const uint32_t od = tab.orient[piece][sk][0];
+    const int aa = stamp_dynamic<W, C>(fb, h, sc, od, pbits);
     int eroded = 0;
     const int kk = clear_lines<W, C>(fb, pbits, &eroded);
     heights_of<W, C>(fb, fh);
     float f[8];
     bcts_features<W, C>(fb, fh, R, hole_lut, aa, (int)((od >> 3) & 7u), eroded, kk, f);
-    emit(s, f);
+    emit(sk, sc, f);
   }
 }
 
@@ -773,10 +788,10 @@ TET_HD void env_step(W (&col)[C], uint64_t& meta, int action, bool use_policy, c
     out.piece = piece;
     return;
   }
-  // decode action -> slot 4c + 2L + o: game.py:69,83
-  const int s = slot_of_action(mask, action);
-  const int c = s >> 2;
-  const uint32_t od = tab.orient[piece][s & 3][0];
+  // decode action -> (orientation field, left column): game.py:69,83
+  int sk, c;
+  slot_of_action<C>(mask, action, sk, c);
+  const uint32_t od = tab.orient[piece][sk][0];
   const int oH = (od >> 3) & 7;
 
   int h[C];

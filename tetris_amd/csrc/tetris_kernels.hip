@@ -298,9 +298,9 @@ __global__ __launch_bounds__(kBlock, TET_AFTER_WAVES) void afterstates_kernel(co
   const int64_t rs = p.row_stride;
   const int nv = tet::popc(valid), na = tet::popc(full);
   float sink = 0.f;
-  tet::afterstates_env<W, C>(col, meta, tab, hole_lut, p.R, [&](int s, float (&f)[8]) {
+  tet::afterstates_env<W, C>(col, meta, tab, hole_lut, p.R, [&](int sk, int sc, float (&f)[8]) {
     if (TET_ABLATE & 64) {  // timing experiment: no feature stores
-      sink += f[0] + f[1] + f[2] + f[3] + f[4] + f[5] + f[6] + f[7] + (float)s;
+      sink += f[0] + f[1] + f[2] + f[3] + f[4] + f[5] + f[6] + f[7] + (float)(sk + sc);
       return;
     }
     if (p.has_direct_by) {
@@ -309,12 +309,12 @@ __global__ __launch_bounds__(kBlock, TET_AFTER_WAVES) void afterstates_kernel(co
     }
     // the row of a placement follows the reference's enumeration order (tet::row_of_slot)
     if (out_all) {
-      float4* d = reinterpret_cast<float4*>(out_all + tet::row_of_slot(full, s) * rs);
+      float4* d = reinterpret_cast<float4*>(out_all + tet::row_of_slot<C>(full, sk, sc) * rs);
       d[0] = make_float4(f[0], f[1], f[2], f[3]);
       d[1] = make_float4(f[4], f[5], f[6], f[7]);
     }
-    if ((valid >> s) & 1) {  // game.py:69
-      float4* d = reinterpret_cast<float4*>(out_valid + tet::row_of_slot(valid, s) * rs);
+    if ((valid >> (C * sk + sc)) & 1) {  // game.py:69
+      float4* d = reinterpret_cast<float4*>(out_valid + tet::row_of_slot<C>(valid, sk, sc) * rs);
       d[0] = make_float4(f[0], f[1], f[2], f[3]);
       d[1] = make_float4(f[4], f[5], f[6], f[7]);
     }
@@ -374,11 +374,11 @@ __global__ __launch_bounds__(kBlock) void greedy_kernel(const GreedyParams p) {
   float* fall = p.fitness_all ? p.fitness_all + i * (int64_t)p.a_max : nullptr;
   float best = 0.f;
   int best_row = -1;
-  tet::afterstates_env<W, C>(col, meta, tab, hole_lut, p.R, [&](int s, float (&f)[8]) {
+  tet::afterstates_env<W, C>(col, meta, tab, hole_lut, p.R, [&](int sk, int sc, float (&f)[8]) {
     const float v = tet::fitness_of(f, p.w);
-    if (fall) fall[tet::row_of_slot(full, s)] = v;
-    if ((valid >> s) & 1) {
-      const int row = tet::row_of_slot(valid, s);
+    if (fall) fall[tet::row_of_slot<C>(full, sk, sc)] = v;
+    if ((valid >> (C * sk + sc)) & 1) {
+      const int row = tet::row_of_slot<C>(valid, sk, sc);
       if (best_row < 0 || v > best || (v == best && row < best_row)) {
         best = v;
         best_row = row;

@@ -55,9 +55,10 @@ inline int n_placements(int pid, int C) {
   return total;
 }
 
-// thresholds: footprint column j needs slack R - h >= need_j = H - b_j; the shift
-// need_j - 1 + 4j picks that level of column c+j's thermometer nibble (valid_mask)
-inline void pack_mask_words(const CatOrient& o, uint32_t* shifts, uint32_t* rescue) {
+// thresholds: footprint column j needs slack R - h >= need_j = H - b_j.  valid_mask keeps the
+// column sets B_l = {c : slack < l} in 16-bit fields of one 64-bit word; the shift
+// 16*(need_j - 1) + j lines column c + j of level need_j up with bit c.
+inline void pack_mask_words(const CatOrient& o, uint32_t* w1, uint32_t* w2, uint32_t* w3) {
   int H = 0;
   for (int j = 0; j < o.w; ++j)
     if (o.b[j] + o.n[j] > H) H = o.b[j] + o.n[j];
@@ -65,9 +66,9 @@ inline void pack_mask_words(const CatOrient& o, uint32_t* shifts, uint32_t* resc
   int first2 = -1;
   for (int j = 0; j < o.w; ++j) {
     const int need = H - o.b[j];
-    sh1[j] = (uint32_t)(need - 1 + 4 * j);
+    sh1[j] = (uint32_t)(16 * (need - 1) + j);
     if (need - 1 >= 1) {
-      sh2[j] = (uint32_t)(need - 2 + 4 * j);
+      sh2[j] = (uint32_t)(16 * (need - 2) + j);
       if (first2 < 0) first2 = j;
     } else {
       sh2[j] = 0xFFu;  // unconstrained once relaxed
@@ -77,14 +78,14 @@ inline void pack_mask_words(const CatOrient& o, uint32_t* shifts, uint32_t* resc
     sh1[j] = sh1[0];
     sh2[j] = 0xFFu;
   }
-  uint32_t sw = 0, rw = 0;
+  uint32_t a = 0, b = 0, r = 0;
   for (int j = 0; j < 4; ++j) {
     if (sh2[j] == 0xFFu) sh2[j] = first2 >= 0 ? sh2[first2] : 0u;
-    sw |= sh1[j] << (4 * j);
-    sw |= sh2[j] << (16 + 4 * j);
+    a |= sh1[j] << (6 * j);
+    b |= sh2[j] << (6 * j);
   }
-  if (first2 < 0) rw |= 1u << 11;
-  if (o.w == 1 && H == 4) rw |= 1u << 10;
+  if (o.w == 1 && H == 4) a |= 1u << 24;
+  if (first2 < 0) a |= 1u << 25;
   for (int t = 1; t < 3; ++t) {  // board row R-3+t holds piece row rho when the anchor is R+1-H
     const int rho = t - 4 + H;
     if (rho < 0 || rho > H - 2) continue;
@@ -94,10 +95,11 @@ inline void pack_mask_words(const CatOrient& o, uint32_t* shifts, uint32_t* resc
         if (j0 < 0) j0 = j;
         j1 = j;
       }
-    rw |= (1u | ((uint32_t)j0 << 1) | ((uint32_t)j1 << 3)) << (5 * (t - 1));
+    r |= (1u | ((uint32_t)j0 << 1) | ((uint32_t)j1 << 3)) << (5 * (t - 1));
   }
-  *shifts = sw;
-  *rescue = rw;
+  *w1 = a;
+  *w2 = b;
+  *w3 = r;
 }
 
 inline void build_table(const TetrisDesc* d, SetTable* t) {
@@ -110,8 +112,8 @@ inline void build_table(const TetrisDesc* d, SetTable* t) {
       for (int oi = 0; oi < p.n_orient[l]; ++oi) {
         uint32_t* e = t->orient[i][l * 2 + oi];
         e[0] = pack_orient(p.o[l][oi]);
-        pack_mask_words(p.o[l][oi], &e[1], &e[2]);
-        for (int c = 0; c + p.o[l][oi].w <= C; ++c) full |= 1ull << (4 * c + 2 * l + oi);
+        pack_mask_words(p.o[l][oi], &e[1], &e[2], &e[3]);
+        for (int c = 0; c + p.o[l][oi].w <= C; ++c) full |= 1ull << (C * (2 * l + oi) + c);
       }
     t->fullmask[i] = full;
   }

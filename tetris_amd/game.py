@@ -16,10 +16,16 @@ from .vec_env import VecTetris
 
 
 
-def _slots_in_action_order(mask):
-    """Slots (4c + 2L + o) of the set bits in the reference's enumeration order."""
-    return [s for s in range(64) if (mask >> s) & 1 and not (s >> 1) & 1] + \
-           [s for s in range(64) if (mask >> s) & 1 and (s >> 1) & 1]
+def _placements_in_action_order(mask, C):
+    """(loop, column, orientation) of the set bits of a valid mask in the reference's
+    enumeration order.  Mask layout: four C-bit fields, field 2L + o, bit c."""
+    out = []
+    for loop in (0, 1):
+        for c in range(C):
+            for o in (0, 1):
+                if (mask >> (C * (2 * loop + o) + c)) & 1:
+                    out.append((loop, c, o))
+    return out
 
 
 class Tetris:
@@ -104,7 +110,7 @@ class Tetris:
         feats = f[0, :n_valid].cpu().numpy()
         feats_all = fa[0, :n_all].cpu().numpy()
         mask = int(self._env.meta[0].item()) & ((1 << 48) - 1)
-        slots = _slots_in_action_order(mask)
+        slots = _placements_in_action_order(mask, self.num_columns)
         assert len(slots) == n_valid
         self._after_slots = slots
         self._after_feats = feats
@@ -136,8 +142,7 @@ class Tetris:
         if not -n_valid <= k < n_valid:  # numpy indexing of self.afterstates: game.py:83
             raise IndexError("index %d is out of bounds for axis 0 with size %d" % (k, n_valid))
         k %= n_valid
-        slot = self._after_slots[k]
-        loop, col, oi = (slot >> 1) & 1, slot >> 2, slot & 1
+        loop, col, oi = self._after_slots[k]
         w, b, n = ORIENTATIONS[self.current_tetromino.name][loop][oi]
         bonus = (max(bj + nj for bj, nj in zip(b, n)) - 1) / 2.0
         nxt = self.tetromino_sampler.next_tetromino()  # game.py:87

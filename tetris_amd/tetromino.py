@@ -55,8 +55,10 @@ def n_placements(name, num_columns):
 
 
 def placement_of_slot(name, num_columns, slot):
-    """Static slot index (bit of the valid mask) -> (loop, column, orientation index)."""
-    return (slot >> 1) & 1, slot >> 2, slot & 1
+    """Bit index of the valid mask (four num_columns-bit fields, field 2*loop + orientation,
+    bit = left column) -> (loop, column, orientation index)."""
+    k, c = divmod(slot, num_columns)
+    return k >> 1, c, k & 1
 
 
 class Tetromino:
