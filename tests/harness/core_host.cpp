@@ -17,9 +17,17 @@
 
 namespace {
 
-const uint8_t kHoleLut[tet::kHoleLutSize] = {
-#include "../../tetris_amd/csrc/tetris_hole_lut.inc"
+struct alignas(16) FeatureLut {
+  uint8_t hole[tet::kHoleLutSize];
+  uint16_t wells[tet::kWellsLutEntries];
 };
+const FeatureLut kFeatureLutHost = {{
+#include "../../tetris_amd/csrc/tetris_hole_lut.inc"
+                                    },
+                                    {
+#include "../../tetris_amd/csrc/tetris_wells_lut.inc"
+                                    }};
+const uint8_t* const kHoleLut = reinterpret_cast<const uint8_t*>(&kFeatureLutHost);
 
 template <typename W, int C>
 void step_impl(const TetrisDesc* desc, void* cols_, uint64_t* meta, const int32_t* action, int32_t* action_out,

@@ -97,8 +97,10 @@ TET_HD uint32_t meta_bag(uint64_t m) { return (uint32_t)(m >> 52); }
 // ---- word helpers -----------------------------------------------------------
 TET_HD int popc(uint32_t x) { return __builtin_popcount(x); }
 TET_HD int popc(uint64_t x) { return __builtin_popcountll(x); }
-TET_HD int bitlen(uint32_t x) { return x ? 32 - __builtin_clz(x) : 0; }
-TET_HD int bitlen(uint64_t x) { return x ? 64 - __builtin_clzll(x) : 0; }
+// bit length (index of the top set bit + 1; 0 for 0).  The top bit of a board word is never
+// used (stored rows < bits(W)), so (x << 1) | 1 is a non-zero word one bit longer: no select.
+TET_HD int bitlen(uint32_t x) { return 31 - __builtin_clz((x << 1) | 1u); }
+TET_HD int bitlen(uint64_t x) { return 63 - __builtin_clzll((x << 1) | 1ull); }
 // (1 << n) - 1 for 0 <= n < bits(W)   (stored rows < bits(W) by contract)
 template <typename W>
 TET_HD W lowmask(int n) { return (W)(((W)1 << n) - 1); }
@@ -186,8 +188,12 @@ struct SetTable {
   uint64_t fullmask[kMaxPieces];   // all existing placements (every one valid)
 };
 
-// hole-depth table (tools/gen_hole_lut.py): 8 KiB, staged in LDS by the kernels
+// feature tables (tools/gen_hole_lut.py), staged in LDS by the kernels as ONE 16 KiB block:
+// bytes [0, 8192): hole-depth table (uint8, 13-bit index); bytes [8192, 16384): wells table
+// (uint16, 12-bit index)
 constexpr int kHoleLutSize = 1 << 13;
+constexpr int kWellsLutEntries = 1 << 12;
+constexpr int kFeatureLutBytes = kHoleLutSize + 2 * kWellsLutEntries;
 
 // bit c -> bit 2c (c < 16)
 TET_HD uint32_t spread2(uint32_t x) {
@@ -288,27 +294,31 @@ TET_HD int clear_lines(W (&col)[C], const W (&pbits)[4], int* eroded_cells) {
 
 // ---- per-column pieces of state.py:175-280 (closed forms of SURVEY App. B) ------------
 // Part that depends on the column alone: holes, column transitions, hole depth.
+// Hole depth (state.py:200,216,239): the top hole of each vertical run counts the filled cells
+// above it.  12-row chunks through the table: entry = A | u << 5 with u the run tops inside
+// the chunk and A their filled cells above inside the chunk; the cells above the chunk count
+// once per run top.  Column transitions (state.py:206,219-220,242-243) below the column top
+// come in pairs, one entering and one leaving every hole run (the floor counts as filled, the
+// top cell is filled), so they are 2 * (number of run tops) -- the same u.
 template <typename W>
 TET_HD void col_own(W x, int hi, int R, const uint8_t* hole_lut, W& ho, int& nh, int& f1, int& f7) {
-  const W mh = lowmask<W>(hi);
-  ho = (W)(~x & mh);                               // holes (state.py:210-213)
+  ho = (W)(~x & lowmask<W>(hi));                   // holes (state.py:210-213)
   nh = popc(ho);
-  f1 = popc((W)((x ^ ((x << 1) | 1)) & mh));       // state.py:206,219-220,242-243
-  // hole depth: the top hole of each vertical run counts the filled cells above it
-  // (state.py:200,216,239).  12-row chunks through the table: entry = A | u << 5 with u the
-  // run tops inside the chunk and A their filled cells above inside the chunk; the cells
-  // above the chunk count once per run top.
-  int d7 = 0;
+  int d7 = 0, u = 0;
   if (!(TET_ABLATE & 16)) {
 #pragma unroll
     for (int k = 0; 12 * k < (int)(8 * sizeof(W)) - 1; ++k) {
       if (k < 2 || 12 * k < R + 4) {  // rows beyond the stored ones are zero: entry 0 adds nothing
         const uint32_t e = hole_lut[(uint32_t)(x >> (12 * k)) & 0x1FFFu];
-        const int above = (12 * (k + 1) < (int)(8 * sizeof(W))) ? popc((W)(x >> (12 * (k + 1)))) : 0;
-        d7 += (int)(e & 31u) + (int)(e >> 5) * above;
+        const int uk = (int)(e >> 5);
+        u += uk;
+        d7 += (int)(e & 31u);
+        if (12 * (k + 1) < (int)(8 * sizeof(W)) && 12 * (k + 1) < R + 4)  // uniform: rows above this chunk exist
+          d7 += uk * popc((W)(x >> (12 * (k + 1))));
       }
     }
   }
+  f1 = 2 * u;
   f7 = d7;
 }
 
@@ -322,31 +332,29 @@ TET_HD int col_rowtrans(W x, W L, int hi, int hL, int nh_left) {
 }
 
 // Cumulative wells of one column (state.py:223-233 inside the column, :258-272 above it).
+// A well cell is an empty cell whose two neighbours are filled: inside the column (rows < h) the
+// walls count as filled on every stored row (state.py:177-178); above it only rows below
+// min(hL, hR) count, with wall height R (state.py:179,258-261) -- neighbours have no cells at or
+// above their own height, so for inner columns the set is simply ~x & L & R, and for the edge
+// columns the wall side is cut at max(h, R).  Every maximal vertical run of k well cells adds
+// k(k+1)/2: summed per 12-row chunk through the wells table (entry = S | lead << 7 | trail << 11)
+// with a carry for runs that cross chunk borders -- no data-dependent loop.
 template <typename W>
-TET_HD int col_wells(W ho, W L, W Rr, int hi, int hL, int hR) {
-  const int top = hL < hR ? hL : hR;
-  const int d = top > hi ? top - hi : 0;
-  const W open = (W)(lowmask<W>(d) << hi);      // rows hi .. top-1
-  const W LR = (W)(L & Rr);
-  const W win = (W)(ho & LR);
-  const W wopen = (W)(LR & open);
-  const bool solid = (wopen == open);           // both neighbours filled over the open range
-  const W w = solid ? win : (W)(win | wopen);
-  int f4 = (solid ? ((d * (d + 1)) >> 1) : 0) + popc(w);
-  // runs of k consecutive rows add k(k+1)/2 in total: level d counts the rows whose run
-  // extends d rows below them; three levels straight-line, deeper (rare) in a loop
-  W t = (TET_ABLATE & 32) ? (W)0 : (W)(w & (w >> 1));
-  f4 += popc(t);
-  t = (W)(t & (t >> 1));
-  f4 += popc(t);
-  t = (W)(t & (t >> 1));
-  f4 += popc(t);
-  t = (W)(t & (t >> 1));
-  while (t != 0) {
-    f4 += popc(t);
-    t = (W)(t & (t >> 1));
+TET_HD int col_wells(W x, W L, W Rr, int hi, int R, bool left_wall, bool right_wall, const uint8_t* lut) {
+  W w = (W)(~x & L & Rr);
+  if (left_wall || right_wall) w = (W)(w & lowmask<W>(hi > R ? hi : R));
+  const uint16_t* wl = reinterpret_cast<const uint16_t*>(lut + kHoleLutSize);
+  int total = 0, carry = 0;
+#pragma unroll
+  for (int k = 0; 12 * k < (int)(8 * sizeof(W)) - 1; ++k) {
+    if (k < 2 || 12 * k < R + 4) {  // rows beyond the stored ones hold no well cells
+      const uint32_t e = wl[(uint32_t)(w >> (12 * k)) & 0xFFFu];
+      const int lead = (int)((e >> 7) & 15u);
+      total += (int)(e & 127u) + carry * lead;
+      carry = (lead == 12) ? carry + 12 : (int)(e >> 11);
+    }
   }
-  return f4;
+  return (TET_ABLATE & 32) ? 0 : total;
 }
 
 // state.py:175-280.  out = f0,f1,f2,f4,f5,f7.
@@ -365,7 +373,6 @@ TET_HD void board_features(const W (&col)[C], const int (&h)[C], int R, const ui
     const W L = (i == 0) ? wall : col[i - 1];
     const W Rr = (i == C - 1) ? wall : col[i + 1];
     const int hL = (i == 0) ? R : h[i - 1];       // state.py:179 wall height = num_rows
-    const int hR = (i == C - 1) ? R : h[i + 1];
     W ho;
     int nh, d1, d7;
     col_own<W>(col[i], h[i], R, hole_lut, ho, nh, d1, d7);
@@ -375,7 +382,7 @@ TET_HD void board_features(const W (&col)[C], const int (&h)[C], int R, const ui
     hole_rows |= ho;                              // state.py:215
     f5 += col_rowtrans<W>(col[i], L, h[i], hL, nh_left);
     nh_left = nh;
-    f4 += col_wells<W>(ho, L, Rr, h[i], hL, hR);
+    f4 += col_wells<W>(col[i], L, Rr, h[i], R, i == 0, i == C - 1, hole_lut);
   }
   rows_with_holes = popc(hole_rows);  // state.py:274-275
   col_trans = f1;
@@ -589,11 +596,10 @@ TET_HD void afterstates_env(const W (&col)[C], uint64_t meta, const SetTable& ta
       const W L = (i == 0) ? wall : col[i - 1];
       const W Rr = (i == C - 1) ? wall : col[i + 1];
       const int hL = (i == 0) ? R : h[i - 1];
-      const int hR = (i == C - 1) ? R : h[i + 1];
       int nh, e1, e7;
       col_own<W>(col[i], h[i], R, hole_lut, HO[i], nh, e1, e7);
       const int e5 = col_rowtrans<W>(col[i], L, h[i], hL, nh_left);
-      const int e4 = col_wells<W>(HO[i], L, Rr, h[i], hL, hR);
+      const int e4 = col_wells<W>(col[i], L, Rr, h[i], R, i == 0, i == C - 1, hole_lut);
       nh_left = nh;
       TA[i] = (uint32_t)e1 | ((uint32_t)nh << 10) | ((uint32_t)e5 << 20);
       TB[i] = (uint32_t)e4 | ((uint32_t)e7 << 16);
@@ -645,8 +651,7 @@ TET_HD void afterstates_env(const W (&col)[C], uint64_t meta, const SetTable& ta
         if (i < c || i > c + 3) hrows |= HO[i];
       if (c >= 1) {  // left neighbour: only its wells see the new column c
         const W L2 = (c >= 2) ? col[cm2] : wall;
-        const int hL2 = (c >= 2) ? h[cm2] : R;
-        dB += (uint32_t)col_wells<W>(HO[cm1], L2, nb[0], h[cm1], hL2, nhh[0]) - (TB[cm1] & 0xFFFFu);
+        dB += (uint32_t)col_wells<W>(col[cm1], L2, nb[0], h[cm1], R, c == 1, false, hole_lut) - (TB[cm1] & 0xFFFFu);
       }
       int nhprev = (c >= 1) ? (int)((TA[cm1] >> 10) & 1023u) : 0;
 #pragma unroll
@@ -659,13 +664,12 @@ TET_HD void afterstates_env(const W (&col)[C], uint64_t meta, const SetTable& ta
           const W L = (j == 0) ? ((c >= 1) ? col[cm1] : wall) : nb[jm];
           const int hL = (j == 0) ? ((c >= 1) ? h[cm1] : R) : nhh[jm];
           const W Rr = (c + j + 1 < C) ? ((j + 1 < 4) ? nb[jp] : col[ip]) : wall;
-          const int hR = (c + j + 1 < C) ? ((j + 1 < 4) ? nhh[jp] : h[ip]) : R;
           if (fullre) {
             W ho;
             int nh, e1, e7;
             col_own<W>(nb[j], nhh[j], R, hole_lut, ho, nh, e1, e7);
             const int e5 = col_rowtrans<W>(nb[j], L, nhh[j], hL, nhprev);
-            const int e4 = col_wells<W>(ho, L, Rr, nhh[j], hL, hR);
+            const int e4 = col_wells<W>(nb[j], L, Rr, nhh[j], R, c + j == 0, c + j == C - 1, hole_lut);
             dA += ((uint32_t)e1 | ((uint32_t)nh << 10) | ((uint32_t)e5 << 20)) - TA[i];
             dB += ((uint32_t)e4 | ((uint32_t)e7 << 16)) - TB[i];
             hrows |= ho;
@@ -674,7 +678,7 @@ TET_HD void afterstates_env(const W (&col)[C], uint64_t meta, const SetTable& ta
             hrows |= HO[i];
             if (part) {  // right neighbour of the widest footprint in this wave
               const int e5 = col_rowtrans<W>(col[i], L, h[i], hL, nhprev);
-              const int e4 = col_wells<W>(HO[i], L, Rr, h[i], hL, hR);
+              const int e4 = col_wells<W>(col[i], L, Rr, h[i], R, false, i == C - 1, hole_lut);
               dA += ((uint32_t)e5 << 20) - (TA[i] & 0xFFF00000u);
               dB += (uint32_t)e4 - (TB[i] & 0xFFFFu);
             }
@@ -685,9 +689,8 @@ TET_HD void afterstates_env(const W (&col)[C], uint64_t meta, const SetTable& ta
       if (c + 4 < C && u3) {  // right neighbour of a 4-wide footprint
         const int i = c + 4 < C ? c + 4 : C - 1, ip = i + 1 < C ? i + 1 : C - 1;
         const W Rr = (c + 5 < C) ? col[ip] : wall;
-        const int hR = (c + 5 < C) ? h[ip] : R;
         dA += ((uint32_t)col_rowtrans<W>(col[i], nb[3], h[i], nhh[3], nhprev) << 20) - (TA[i] & 0xFFF00000u);
-        dB += (uint32_t)col_wells<W>(HO[i], nb[3], Rr, h[i], nhh[3], hR) - (TB[i] & 0xFFFFu);
+        dB += (uint32_t)col_wells<W>(col[i], nb[3], Rr, h[i], R, false, i == C - 1, hole_lut) - (TB[i] & 0xFFFFu);
       }
       const int lj = (C - 1 - c >= 0 && C - 1 - c < 4) ? C - 1 - c : 0;
       const int pl = (C - 1 >= c && C - 1 < c + 4) ? popc(nb[lj]) : plast;

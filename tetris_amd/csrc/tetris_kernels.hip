@@ -29,15 +29,24 @@ constexpr int kBlock = 256;
 
 // ---- kernels ------------------------------------------------------------------
 
-// hole-depth table (8 KiB; tools/gen_hole_lut.py), copied to LDS by the kernels that compute features
-__device__ const uint8_t kHoleLut[tet::kHoleLutSize] = {
-#include "tetris_hole_lut.inc"
+// feature tables (tools/gen_hole_lut.py): hole depth (8 KiB of uint8) followed by wells (8 KiB of
+// uint16), copied to LDS as one block by the kernels that compute features
+struct alignas(16) FeatureLut {
+  uint8_t hole[tet::kHoleLutSize];
+  uint16_t wells[tet::kWellsLutEntries];
 };
+__device__ const FeatureLut kFeatureLut = {{
+#include "tetris_hole_lut.inc"
+                                           },
+                                           {
+#include "tetris_wells_lut.inc"
+                                           }};
+static_assert(sizeof(FeatureLut) == tet::kFeatureLutBytes, "layout assumed by col_wells");
 
 __device__ __forceinline__ void stage_hole_lut(uint8_t* lds) {
-  const uint4* src = reinterpret_cast<const uint4*>(kHoleLut);
+  const uint4* src = reinterpret_cast<const uint4*>(&kFeatureLut);
   uint4* dst = reinterpret_cast<uint4*>(lds);
-  for (int t = threadIdx.x; t < tet::kHoleLutSize / 16; t += blockDim.x) dst[t] = src[t];
+  for (int t = threadIdx.x; t < tet::kFeatureLutBytes / 16; t += blockDim.x) dst[t] = src[t];
 }
 
 __device__ __forceinline__ void stage_table(SetTable& lds, const SetTable& arg) {
@@ -118,7 +127,7 @@ __device__ __forceinline__ void load_inputs(const StepParams& p, uint32_t i, Ste
 template <typename W, int C>
 __global__ __launch_bounds__(kBlock, TET_STEP_WAVES) void step_kernel(const StepParams p) {
   __shared__ SetTable tab;
-  __shared__ __attribute__((aligned(16))) uint8_t hole_lut[tet::kHoleLutSize];
+  __shared__ __attribute__((aligned(16))) uint8_t hole_lut[tet::kFeatureLutBytes];
   __shared__ W lane_cols[C][kBlock];  // per-lane scratch for the runtime-indexed stamp (bank = lane)
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
   const bool live = i < p.B;
@@ -127,14 +136,17 @@ __global__ __launch_bounds__(kBlock, TET_STEP_WAVES) void step_kernel(const Step
   StepInputs<W, C> in;
   load_inputs<W, C>(p, i, in);
   {
-    static_assert(tet::kHoleLutSize == kBlock * 32, "two 16-byte pieces of the table per lane");
+    static_assert(tet::kFeatureLutBytes == kBlock * 64, "four 16-byte pieces of the tables per lane");
     static_assert(sizeof(SetTable) / 4 <= kBlock, "one table word per lane");
-    const uint4* lsrc = reinterpret_cast<const uint4*>(kHoleLut);
+    const uint4* lsrc = reinterpret_cast<const uint4*>(&kFeatureLut);
     const uint4 l0 = lsrc[threadIdx.x], l1 = lsrc[threadIdx.x + kBlock];
+    const uint4 l2 = lsrc[threadIdx.x + 2 * kBlock], l3 = lsrc[threadIdx.x + 3 * kBlock];
     const uint32_t* tsrc = reinterpret_cast<const uint32_t*>(&p.tab);
     const uint32_t tw = threadIdx.x < sizeof(SetTable) / 4 ? tsrc[threadIdx.x] : 0u;
     reinterpret_cast<uint4*>(hole_lut)[threadIdx.x] = l0;
     reinterpret_cast<uint4*>(hole_lut)[threadIdx.x + kBlock] = l1;
+    reinterpret_cast<uint4*>(hole_lut)[threadIdx.x + 2 * kBlock] = l2;
+    reinterpret_cast<uint4*>(hole_lut)[threadIdx.x + 3 * kBlock] = l3;
     if (threadIdx.x < sizeof(SetTable) / 4) reinterpret_cast<uint32_t*>(&tab)[threadIdx.x] = tw;
     __syncthreads();
   }
@@ -277,7 +289,7 @@ struct AfterParams {
 template <typename W, int C>
 __global__ __launch_bounds__(kBlock, TET_AFTER_WAVES) void afterstates_kernel(const AfterParams p) {
   __shared__ SetTable tab;
-  __shared__ __attribute__((aligned(16))) uint8_t hole_lut[tet::kHoleLutSize];
+  __shared__ __attribute__((aligned(16))) uint8_t hole_lut[tet::kFeatureLutBytes];
   stage_hole_lut(hole_lut);
   stage_table(tab, p.tab);
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -358,7 +370,7 @@ struct GreedyParams {
 template <typename W, int C>
 __global__ __launch_bounds__(kBlock) void greedy_kernel(const GreedyParams p) {
   __shared__ SetTable tab;
-  __shared__ __attribute__((aligned(16))) uint8_t hole_lut[tet::kHoleLutSize];
+  __shared__ __attribute__((aligned(16))) uint8_t hole_lut[tet::kFeatureLutBytes];
   stage_hole_lut(hole_lut);
   stage_table(tab, p.tab);
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
