@@ -22,10 +22,14 @@ using tet::check_desc;
 
 constexpr int kBlock = 256;
 
-// minimum waves per SIMD the step kernel is compiled for (bounds its VGPR budget)
+// minimum waves per SIMD the step kernel is compiled for (bounds its VGPR budget).  u32 boards:
+// 5 (96 VGPRs, 3 spilled dwords; measured 3 % faster than the unconstrained 100 VGPRs / 4 waves;
+// 27 KiB of LDS per workgroup allow 5 workgroups per CU anyway).  u64 boards need ~136 VGPRs.
 #ifndef TET_STEP_WAVES
-#define TET_STEP_WAVES 1
+#define TET_STEP_WAVES 0
 #endif
+template <typename W>
+constexpr int step_waves() { return TET_STEP_WAVES ? TET_STEP_WAVES : (sizeof(W) == 4 ? 5 : 1); }
 
 // ---- kernels ------------------------------------------------------------------
 
@@ -125,7 +129,7 @@ __device__ __forceinline__ void load_inputs(const StepParams& p, uint32_t i, Ste
 // next tile was measured and is slower: the kernel is bound by integer-VALU issue, not by
 // exposed memory latency, and the prefetch registers cost occupancy.)
 template <typename W, int C>
-__global__ __launch_bounds__(kBlock, TET_STEP_WAVES) void step_kernel(const StepParams p) {
+__global__ __launch_bounds__(kBlock, step_waves<W>()) void step_kernel(const StepParams p) {
   __shared__ SetTable tab;
   __shared__ __attribute__((aligned(16))) uint8_t hole_lut[tet::kFeatureLutBytes];
   __shared__ W lane_cols[C][kBlock];  // per-lane scratch for the runtime-indexed stamp (bank = lane)

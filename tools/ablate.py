@@ -25,7 +25,7 @@ libs = {}
 for m in masks:
     out = "/tmp/libtetris_abl_%d.so" % m
     subprocess.check_call([build._hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC",
-                           "-DTET_ABLATE=%d" % (m % 1000), "-DTET_STEP_WAVES=%d" % max(1, m // 1000)] + extra +
+                           "-DTET_ABLATE=%d" % (m % 1000), "-DTET_STEP_WAVES=%d" % (m // 1000)] + extra +
                           [src, "-o", out])
     libs[m] = _lib._Binding(ctypes.CDLL(out))
 

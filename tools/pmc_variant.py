@@ -18,7 +18,7 @@ out = "/tmp/libtetris_abl_%d.so" % m
 if not os.path.exists(out):
     src = os.path.join(ROOT, "tetris_amd", "csrc", "tetris_kernels.hip")
     subprocess.check_call([build._hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC",
-                           "-DTET_ABLATE=%d" % (m % 1000), "-DTET_STEP_WAVES=%d" % max(1, m // 1000), src, "-o", out])
+                           "-DTET_ABLATE=%d" % (m % 1000), "-DTET_STEP_WAVES=%d" % (m // 1000), src, "-o", out])
 env = VecTetris(10, rows, 1 << 20, device="cuda", auto_reset=True, seed=0)
 for t in range(150):
     env.step()
