@@ -31,8 +31,10 @@ class OrcDesc(ctypes.Structure):
 
 
 def build(force=False):
+    """Build the oracle if it is missing (or sources are newer and we are in the authoring tree)."""
     src = [os.path.join(_HERE, f) for f in ("tetris_oracle.c", "tetris_oracle.h")]
-    if force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in src):
+    stale = os.path.exists(_SO) and any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in src)
+    if force or not os.path.exists(_SO) or (stale and os.environ.get("TETRIS_ORACLE_NO_REBUILD") != "1"):
         subprocess.check_call(["make", "-C", _HERE, "-B", "libtetris_oracle.so"], stdout=subprocess.DEVNULL)
     return _SO
 

@@ -89,14 +89,16 @@ _BINDING = None
 
 
 def load():
-    """Load (building if the sources are newer and hipcc exists) libtetris_hip.so."""
+    """Load libtetris_hip.so.  A missing library is built once if hipcc is available (an existing
+    one is never rebuilt implicitly: N ranks start at once and file times do not survive copies;
+    use `python -m tetris_amd.build` or TETRIS_AMD_REBUILD=1 after editing csrc/)."""
     global _BINDING
     if _BINDING is not None:
         return _BINDING
     path = _build.SO_PATH
-    if _build.is_stale():
+    if not os.path.exists(path) or os.environ.get("TETRIS_AMD_REBUILD") == "1":
         try:
-            _build.build_hip()
+            _build.build_hip(force=True)
         except Exception as exc:  # no hipcc on this machine
             if not os.path.exists(path):
                 raise ImportError(
@@ -105,7 +107,8 @@ def load():
     cdll = ctypes.CDLL(path)
     b = _Binding(cdll)
     if b.version() != ABI_VERSION:
-        raise ImportError("libtetris_hip.so ABI %d != expected %d" % (b.version(), ABI_VERSION))
+        raise ImportError("libtetris_hip.so ABI %d != expected %d: rebuild with `python -m tetris_amd.build`"
+                          % (b.version(), ABI_VERSION))
     _BINDING = b
     return b
 

@@ -28,11 +28,17 @@ def build_hip(force=False, verbose=False):
     """Compile the HIP kernels + C-ABI for gfx950 into tetris_amd/csrc/libtetris_hip.so."""
     if not force and not is_stale():
         return SO_PATH
+    tmp = "%s.%d.tmp" % (SO_PATH, os.getpid())  # build aside, then rename: never a half-written .so
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC",
-           os.path.join(_CSRC, "tetris_kernels.hip"), "-o", SO_PATH]
+           os.path.join(_CSRC, "tetris_kernels.hip"), "-o", tmp]
     if verbose:
         print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    try:
+        subprocess.check_call(cmd)
+        os.replace(tmp, SO_PATH)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
     return SO_PATH
 
 
