@@ -171,6 +171,21 @@ int tetris_hip_policy_greedy(const TetrisDesc* desc, const void* cols, const uin
                              const float* weights, int32_t* best_action, float* best_value,
                              float* fitness_all, int64_t B, void* hip_stream);
 
+/*
+ * Tetris.perform_rollouts / single_rollout (game.py:129-160) as a batch fan-out: for every env
+ * and every valid first action a, `n` rollouts of `length` steps with the board kept in
+ * registers.  returns[i][a] (double[B][a_max]) = mean over the n rollouts of the rollout return
+ * (game.py:133-146: -1 if the env is already over or dies at any step, else the sum of the
+ * rewards of steps 2..length); NaN for a >= n_valid.
+ *  policy  : 0 uniform random valid action, 1 greedy on `weights` (HOST pointer to 8 floats)
+ * cols / meta are not modified (the reference restores the env after every rollout but lets
+ * its global bag advance; here every rollout draws from its own fork of the env's bag).
+ */
+int tetris_hip_rollouts(const TetrisDesc* desc, const void* cols, const uint64_t* meta,
+                        double* returns, int32_t length, int32_t n, int32_t policy,
+                        const float* weights, uint64_t seed, uint64_t step_idx,
+                        int64_t env_offset, int64_t B, void* hip_stream);
+
 /* uniform random valid action per env: floor(u * n_valid), u from the
  * counter-based hash (the probe policy of SURVEY section 6 / example_play) */
 int tetris_hip_policy_random(const uint8_t* n_valid, int32_t* action, uint64_t seed,

@@ -154,6 +154,17 @@ class OracleVecEnv:
         self.step_idx += 1
         return self.obs, self.reward, self.done, self.lines, n_bad
 
+    def rollouts(self, length=5, n=5, policy="random", weights=(-24.04, -19.77, -13.08, -12.63, -10.49, -9.22, 6.6,
+                                                                  -1.61)):
+        am = a_max(self.desc)
+        out = np.zeros((self.B, am), np.float64)
+        w = np.asarray(weights, np.float32)
+        lib().orc_rollouts_batch(
+            ctypes.byref(self.desc), _p(self.cells), _p(self.piece), _p(self.bag), _p(out), am, int(length), int(n),
+            {"random": 0, "greedy": 1}[policy], _p(w), ctypes.c_uint64(self.seed), ctypes.c_uint64(self.step_idx),
+            ctypes.c_int64(self.env_offset), ctypes.c_int64(self.B), self.nthreads)
+        return out
+
     def afterstates(self, include_terminal=False):
         am = a_max(self.desc)
         feats = np.zeros((self.B, am, 8), np.float32)

@@ -584,3 +584,124 @@ void orc_np_permutation(uint32_t* st, int n, int32_t* out) {
     out[v] = t;
   }
 }
+
+/* ----- rollouts (game.py:129-160), with the build's per-rollout bag fork ------------------
+ * returns[i][a] = mean over n of single_rollout(a): -1 when the env is over already or dies at
+ * any step, else the sum of the rewards of steps 2..length.  policy 0 = the build's uniform
+ * random policy, 1 = greedy on the float32 fitness of game.py:107-120 (first maximum among the
+ * non-terminal placements). */
+static uint32_t hash_key32(uint64_t seed, uint64_t counter) {
+  uint32_t k = mix32((uint32_t)seed ^ 0x9E3779B9U);
+  k = mix32(k ^ (uint32_t)(seed >> 32));
+  k = mix32(k ^ (uint32_t)counter);
+  k = mix32(k ^ (uint32_t)(counter >> 32));
+  return k;
+}
+
+static uint32_t hash_env32(uint32_t key, uint32_t env) {
+  uint32_t h = (key ^ env) * 0x9E3779B1U;
+  h ^= h >> 16;
+  h *= 0x85EBCA6BU;
+  h ^= h >> 13;
+  return h;
+}
+
+static float fitness32(const float f[8], const float w[8]) {
+  volatile float acc = f[0] * w[0]; /* every product and partial sum rounded to float32 */
+  for (int q = 1; q < 8; ++q) {
+    volatile float prod = f[q] * w[q];
+    acc = acc + prod;
+  }
+  return acc;
+}
+
+void orc_rollouts_batch(const OrcDesc* d, const int8_t* cells, const int32_t* piece, const uint16_t* bag,
+                        double* returns, int a_max, int length, int n, int policy, const float* weights,
+                        uint64_t seed, uint64_t step_idx, int64_t env_offset, int64_t B, int nthreads) {
+  const int C = d->num_columns, rows = d->num_rows + 4;
+  const uint32_t key = hash_key32(seed ^ 0x526F6C6C6F757473ULL, step_idx);
+#ifdef _OPENMP
+  if (nthreads > 0) omp_set_num_threads(nthreads);
+#pragma omp parallel for schedule(dynamic, 1) if (nthreads != 1)
+#endif
+  for (int64_t i = 0; i < B; ++i) {
+    OrcState after[ORC_MAX_PLACEMENTS];
+    OrcState start;
+    state_from_flat(d, cells + i * rows * C, &start);
+    int n0 = orc_enumerate(d, &start, d->piece_ids[piece[i]], after);
+    int nv0 = 0;
+    for (int k = 0; k < n0; ++k) nv0 += !after[k].terminal;
+    for (int a0 = 0; a0 < a_max; ++a0) {
+      if (a0 >= nv0) {
+        returns[i * a_max + a0] = __builtin_nan("");
+        continue;
+      }
+      int sum = 0;
+      for (int r = 0; r < n; ++r) {
+        const uint64_t uid = ((uint64_t)(env_offset + i) * (uint64_t)a_max + (uint64_t)a0) * (uint64_t)n + (uint64_t)r;
+        const uint32_t key0 = mix32(key ^ ((uint32_t)(uid >> 32) * 0x9E3779B1U));
+        OrcState cur = start;
+        int cur_piece = piece[i];
+        uint16_t cur_bag = bag[i];
+        int ret = 0;
+        for (int t = 0; t < length; ++t) {
+          const uint32_t key_step = mix32(key0 + 2u * (uint32_t)t), key_pol = mix32(key0 + 2u * (uint32_t)t + 1u);
+          int m = orc_enumerate(d, &cur, d->piece_ids[cur_piece], after);
+          int nv = 0;
+          for (int k = 0; k < m; ++k) nv += !after[k].terminal;
+          if (nv == 0) { /* cannot happen after a non-done step; covers the already-over start */
+            ret = -1;
+            break;
+          }
+          int act = a0;
+          if (t > 0) {
+            if (policy == 0) {
+              act = (int)(((hash_env32(key_pol, (uint32_t)uid) >> 16) * (uint32_t)nv) >> 16);
+            } else {
+              float best = 0.f;
+              int best_row = -1, row = 0;
+              for (int k = 0; k < m; ++k) {
+                if (after[k].terminal) continue;
+                float f[8];
+                orc_features(d, &after[k], f);
+                float v = fitness32(f, weights);
+                if (best_row < 0 || v > best) {
+                  best = v;
+                  best_row = row;
+                }
+                ++row;
+              }
+              act = best_row;
+            }
+          }
+          int chosen = -1, seen = 0;
+          for (int k = 0; k < m; ++k) {
+            if (after[k].terminal) continue;
+            if (seen == act) chosen = k;
+            ++seen;
+          }
+          OrcState nxt = after[chosen];
+          int np_ = orc_bag_draw(&cur_bag, d->n_pieces, hash_env32(key_step, (uint32_t)uid) >> 16);
+          int nvn = 0;
+          {
+            OrcState tmp[ORC_MAX_PLACEMENTS];
+            int mm = orc_enumerate(d, &nxt, d->piece_ids[np_], tmp);
+            for (int k = 0; k < mm; ++k) nvn += !tmp[k].terminal;
+          }
+          int done = (nvn == 0);
+          int rew = nxt.n_cleared - 1 + (done ? -100 : 0);
+          if (done) {
+            ret = -1;
+            break;
+          }
+          if (t > 0) ret += rew;
+          cur = nxt;
+          cur_piece = np_;
+        }
+        sum += ret;
+      }
+      returns[i * a_max + a0] = (double)sum / (double)n;
+    }
+  }
+}
+

@@ -117,6 +117,12 @@ void orc_afterstates_batch(const OrcDesc* d, const int8_t* cells,
                            uint8_t* n_valid, float* feats_all, uint8_t* n_all,
                            int64_t B, int nthreads);
 
+/* game.py:129-160 perform_rollouts as a fan-out over (env, first action), with the build's
+ * hash-driven policies / per-rollout bag fork.  returns [B][a_max] (NaN beyond n_valid). */
+void orc_rollouts_batch(const OrcDesc* d, const int8_t* cells, const int32_t* piece, const uint16_t* bag,
+                        double* returns, int a_max, int length, int n, int policy, const float* weights,
+                        uint64_t seed, uint64_t step_idx, int64_t env_offset, int64_t B, int nthreads);
+
 /* counter-based bag draw shared with the HIP kernel (build design, not from
  * the reference; same distribution as tetromino.py:12-22). */
 uint32_t orc_hash32(uint64_t seed, uint64_t env, uint64_t counter);

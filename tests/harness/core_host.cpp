@@ -302,6 +302,43 @@ int tetris_host_policy_greedy(const TetrisDesc* desc, const void* cols_, const u
   });
 }
 
+int tetris_host_rollouts(const TetrisDesc* desc, const void* cols_, const uint64_t* meta, double* returns,
+                         int32_t length, int32_t n, int32_t policy, const float* weights, uint64_t seed,
+                         uint64_t step_idx, int64_t env_offset, int64_t B, void* unused) {
+  (void)unused;
+  return dispatch(desc, [&](auto wt, auto ct) {
+    using W = decltype(wt);
+    constexpr int C = decltype(ct)::value;
+    tet::SetTable tab;
+    tet::build_table(desc, &tab);
+    float w[8];
+    for (int q = 0; q < 8; ++q) w[q] = weights ? weights[q] : 0.f;
+    const uint32_t key = tet::hash_key(seed ^ 0x526F6C6C6F757473ull, step_idx);
+    const W* cols = static_cast<const W*>(cols_);
+    const int a_max = desc->a_max;
+    for (int64_t i = 0; i < B; ++i) {
+      W col[C];
+      for (int c = 0; c < C; ++c) col[c] = cols[(int64_t)c * B + i];
+      const int nv = tet::popc(tet::meta_mask(meta[i]));
+      for (int a0 = 0; a0 < a_max; ++a0) {
+        double mean = __builtin_nan("");
+        if (a0 < nv) {
+          int sum = 0;
+          for (int r = 0; r < n; ++r) {
+            const uint64_t uid = ((uint64_t)(env_offset + i) * (uint64_t)a_max + (uint64_t)a0) * (uint64_t)n + r;
+            const uint32_t key0 = tet::mix32(key ^ ((uint32_t)(uid >> 32) * 0x9E3779B1u));
+            W scratch[C];
+            sum += tet::rollout_env<W, C>(col, meta[i], a0, length, policy, w, tab, kHoleLut, scratch, 1,
+                                          desc->num_rows, desc->n_pieces, key0, (uint32_t)uid);
+          }
+          mean = (double)sum / (double)n;
+        }
+        returns[i * a_max + a0] = mean;
+      }
+    }
+  });
+}
+
 int tetris_host_version(void) { return TETRIS_HIP_ABI_VERSION; }
 
 int64_t tetris_host_status_words(int64_t B) { return B <= 0 ? 0 : 4 * (((B + 255) / 256) * 4); }

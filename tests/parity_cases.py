@@ -325,3 +325,24 @@ def greedy_policy(device, orc, golden_dir, B=400):
             pol /= pol.sum()
             np.testing.assert_array_equal(pol, pol_ref[:k])
             np.testing.assert_array_equal(f, g[tag + "_fitness"][t][:k].astype(np.float32))
+
+
+def rollouts(device, orc, B=96):
+    """tetris_hip_rollouts (game.py:129-160 fan-out) vs the oracle, both policies, mid-game boards."""
+    from tetris_amd import VecTetris
+    for pieces, R, seed in (("default", 20, 5), ("standard7", 12, 6)):
+        env = VecTetris(10, R, B, device=device, pieces=pieces, auto_reset=False, seed=seed)
+        ref = orc.OracleVecEnv(10, R, B, pieces=pieces, auto_reset=False, seed=seed, nthreads=0)
+        for t in range(int(R * 1.6)):  # play towards the top so that rollouts do die
+            env.step()
+            ref.step()
+        np.testing.assert_array_equal(env.boards().cpu().numpy(), ref.cells)
+        before = (env.cols.clone(), env.meta.clone())
+        for policy, length, n in (("random", 5, 5), ("random", 8, 3), ("greedy", 4, 2)):
+            got = env.rollouts(length=length, n=n, policy=policy).cpu().numpy()
+            want = ref.rollouts(length=length, n=n, policy=policy)
+            np.testing.assert_array_equal(np.isnan(got), np.isnan(want))
+            np.testing.assert_array_equal(np.nan_to_num(got, nan=7.0), np.nan_to_num(want, nan=7.0))
+            vals = np.unique(got[~np.isnan(got)])
+            assert len(vals) > 2, vals  # deaths (-1 in the mean) and survivals both occur
+        assert torch.equal(env.cols, before[0]) and torch.equal(env.meta, before[1])  # envs untouched

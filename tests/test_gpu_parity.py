@@ -101,3 +101,7 @@ def test_integration_md_stub_runs():
         hb.step(a, seed=5)
         env.step(a)
         assert torch.equal(hb.cols, env.cols) and torch.equal(hb.obs, env.obs) and torch.equal(hb.meta, env.meta)
+
+
+def test_rollouts(orc):
+    pc.rollouts(DEV, orc)

@@ -51,3 +51,7 @@ def test_step_without_obs(host_backend, orc):
 
 def test_greedy_policy(host_backend, orc, golden_dir):
     pc.greedy_policy(DEV, orc, golden_dir)
+
+
+def test_rollouts(host_backend, orc):
+    pc.rollouts(DEV, orc)

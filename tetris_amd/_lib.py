@@ -46,6 +46,7 @@ SIGNATURES = {
                         _i64, _i64, _vp],
     "tetris_hip_afterstates": [_dp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp],
     "tetris_hip_policy_greedy": [_dp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
+    "tetris_hip_rollouts": [_dp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _u64, _u64, _i64, _i64, _vp],
     "tetris_hip_policy_random": [_vp, _vp, _u64, _u64, _i64, _i64, _vp],
     "tetris_hip_decode": [_dp, _vp, _vp, _vp, _i64, _vp],
     "tetris_hip_encode": [_dp, _vp, _vp, _i64, _vp],

@@ -835,4 +835,63 @@ TET_HD void env_step(W (&col)[C], uint64_t& meta, int action, bool use_policy, c
   meta = meta_pack(nmask, np, bag);
 }
 
+// ---- rollouts (game.py:129-160) --------------------------------------------------------------
+// One rollout of `length` steps from (col, meta) starting with first action `a0`:
+// returns -1 if the env is already over, dies on the first step or on any later one, else the
+// sum of the rewards of steps 2..length (game.py:133-146; the first reward is not counted).
+// policy 0: uniform random valid action; 1: greedy on the linear fitness `w` (first maximum).
+// Pieces come from a fork of the env's bag driven by hash(key0 + t, uid); the env is untouched.
+template <typename W, int C>
+TET_HD int rollout_env(const W (&col0)[C], uint64_t meta0, int a0, int length, int policy, const float (&w)[8],
+                       const SetTable& tab, const uint8_t* hole_lut, W* scratch, int sstride, int R, int n_pieces,
+                       uint32_t key0, uint32_t uid) {
+  W col[C];
+#pragma unroll
+  for (int i = 0; i < C; ++i) col[i] = col0[i];
+  uint64_t meta = meta0;
+  if (popc(meta_mask(meta)) == 0) return -1;  // game.py:132-133
+  StepCfg cfg;
+  cfg.R = R;
+  cfg.n_pieces = n_pieces;
+  cfg.auto_reset = 0;
+  cfg.has_direct_by = 0;
+  cfg.compute_obs = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) cfg.direct_by[i] = 1.0f;
+  int ret = 0;
+#pragma unroll 1
+  for (int t = 0; t < length; ++t) {
+    cfg.key_step = mix32(key0 + 2u * (uint32_t)t);
+    cfg.key_policy = mix32(key0 + 2u * (uint32_t)t + 1u);
+    int action = a0;
+    bool use_policy = false;
+    if (t > 0) {
+      if (policy == 0) {
+        use_policy = true;
+        action = -1;
+      } else {  // greedy: first non-terminal action of maximal fitness (game.py:102-120 on valid ones)
+        const uint64_t valid = meta_mask(meta);
+        float best = 0.f;
+        int best_row = -1;
+        afterstates_env<W, C>(col, meta, tab, hole_lut, R, [&](int sk, int sc, float (&f)[8]) {
+          if ((valid >> (C * sk + sc)) & 1) {
+            const float v = fitness_of(f, w);
+            const int row = row_of_slot<C>(valid, sk, sc);
+            if (best_row < 0 || v > best || (v == best && row < best_row)) {
+              best = v;
+              best_row = row;
+            }
+          }
+        });
+        action = best_row;
+      }
+    }
+    StepOut out;
+    env_step<W, C>(col, meta, action, use_policy, tab, hole_lut, scratch, sstride, cfg, uid, -1, -1, out);
+    if (out.done || out.invalid) return -1;  // game.py:135-138,143-145
+    if (t > 0) ret += out.reward;
+  }
+  return ret;
+}
+
 }  // namespace tet

@@ -407,6 +407,56 @@ __global__ __launch_bounds__(kBlock) void greedy_kernel(const GreedyParams p) {
   if (p.best_value) p.best_value[i] = best;
 }
 
+struct RolloutParams {
+  const void* cols;
+  const uint64_t* meta;
+  double* returns;  // [B][a_max]
+  int64_t B;
+  int64_t env_offset;
+  int32_t R;
+  int32_t a_max;
+  int32_t n_pieces;
+  int32_t length;
+  int32_t n;
+  int32_t policy;
+  uint32_t key;
+  float w[8];
+  SetTable tab;
+};
+
+// Tetris.perform_rollouts (game.py:150-160) as a fan-out: one lane per (env, first action) runs its
+// n rollouts back to back with the board in registers; nothing but the mean returns is written.
+template <typename W, int C>
+__global__ __launch_bounds__(kBlock) void rollouts_kernel(const RolloutParams p) {
+  __shared__ SetTable tab;
+  __shared__ __attribute__((aligned(16))) uint8_t hole_lut[tet::kFeatureLutBytes];
+  __shared__ W lane_cols[C][kBlock];
+  stage_hole_lut(hole_lut);
+  stage_table(tab, p.tab);
+  const int64_t id = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (id >= p.B * p.a_max) return;
+  const int64_t i = id / p.a_max;
+  const int a0 = (int)(id - i * p.a_max);
+  const W* cols = static_cast<const W*>(p.cols);
+  W col[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) col[c] = cols[(int64_t)c * p.B + i];
+  const uint64_t meta = p.meta[i];
+  const int nv = tet::popc(tet::meta_mask(meta));
+  double mean = __longlong_as_double(0x7FF8000000000000ll);  // NaN: not an action of this env
+  if (a0 < nv) {
+    int sum = 0;
+    for (int r = 0; r < p.n; ++r) {
+      const uint64_t uid = ((uint64_t)(p.env_offset + i) * (uint64_t)p.a_max + (uint64_t)a0) * (uint64_t)p.n + r;
+      const uint32_t key0 = tet::mix32(p.key ^ ((uint32_t)(uid >> 32) * 0x9E3779B1u));
+      sum += tet::rollout_env<W, C>(col, meta, a0, p.length, p.policy, p.w, tab, hole_lut,
+                                    &lane_cols[0][threadIdx.x], kBlock, p.R, p.n_pieces, key0, (uint32_t)uid);
+    }
+    mean = (double)sum / (double)p.n;
+  }
+  p.returns[id] = mean;
+}
+
 __global__ __launch_bounds__(kBlock) void policy_random_kernel(const uint8_t* __restrict__ n_valid,
                                                                int32_t* __restrict__ action, uint32_t key,
                                                                int64_t env_offset, int64_t B) {
@@ -476,6 +526,12 @@ template <typename W, int C>
 struct LaunchRefresh {
   static void run(const RefreshParams& p, hipStream_t s) {
     hipLaunchKernelGGL((refresh_kernel<W, C>), grid_for(p.B), dim3(kBlock), 0, s, p);
+  }
+};
+template <typename W, int C>
+struct LaunchRollouts {
+  static void run(const RolloutParams& p, hipStream_t s) {
+    hipLaunchKernelGGL((rollouts_kernel<W, C>), grid_for(p.B * p.a_max), dim3(kBlock), 0, s, p);
   }
 };
 template <typename W, int C>
@@ -647,6 +703,31 @@ int tetris_hip_policy_greedy(const TetrisDesc* desc, const void* cols, const uin
   for (int i = 0; i < 8; ++i) p.w[i] = weights[i];
   build_table(desc, &p.tab);
   return dispatch<LaunchGreedy>(desc, p, (hipStream_t)hip_stream);
+}
+
+int tetris_hip_rollouts(const TetrisDesc* desc, const void* cols, const uint64_t* meta, double* returns,
+                        int32_t length, int32_t n, int32_t policy, const float* weights, uint64_t seed,
+                        uint64_t step_idx, int64_t env_offset, int64_t B, void* hip_stream) {
+  int rc = check_desc(desc);
+  if (rc) return rc;
+  if (!cols || !meta || !returns || (policy == 1 && !weights)) return TETRIS_E_NULL;
+  if (B <= 0 || length < 1 || n < 1 || policy < 0 || policy > 1) return TETRIS_E_BATCH;
+  RolloutParams p;
+  p.cols = cols;
+  p.meta = meta;
+  p.returns = returns;
+  p.B = B;
+  p.env_offset = env_offset;
+  p.R = desc->num_rows;
+  p.a_max = desc->a_max;
+  p.n_pieces = desc->n_pieces;
+  p.length = length;
+  p.n = n;
+  p.policy = policy;
+  p.key = tet::hash_key(seed ^ 0x526F6C6C6F757473ull, step_idx);
+  for (int i = 0; i < 8; ++i) p.w[i] = weights ? weights[i] : 0.f;
+  build_table(desc, &p.tab);
+  return dispatch<LaunchRollouts>(desc, p, (hipStream_t)hip_stream);
 }
 
 int tetris_hip_refresh(const TetrisDesc* desc, const void* cols, uint64_t* meta, uint8_t* n_valid_out,

@@ -219,6 +219,20 @@ class VecTetris:
             return self._best_action, self._best_value, fa
         return self._best_action, self._best_value
 
+    def rollouts(self, length=5, n=5, policy="random", weights=None):
+        """Tetris.perform_rollouts (game.py:150-160) for every env and every valid first action:
+        ``returns float64 [B, a_max]`` = mean rollout return over ``n`` rollouts of ``length`` steps
+        (NaN where the action does not exist).  ``policy`` = "random" or "greedy" (linear fitness
+        on ``weights``, default the BCTS weights of game.py:111-118).  The envs are not modified."""
+        pol = {"random": 0, "greedy": 1}[policy]
+        w = (ctypes.c_float * 8)(*(self.BCTS_WEIGHTS if weights is None else [float(x) for x in weights]))
+        out = torch.empty((self.batch_size, self.a_max), dtype=torch.float64, device=self.device)
+        rc = self._lib.rollouts(ctypes.byref(self.desc), _ptr(self.cols), _ptr(self.meta), _ptr(out), int(length),
+                                int(n), pol, w, self.seed, self.step_idx, self.env_offset, self.batch_size,
+                                self._hip_stream())
+        self._lib.check(rc, "tetris_hip_rollouts")
+        return out
+
     def random_actions(self, out=None):
         """Uniform random valid action per env (the random-rollout policy)."""
         out = self.action if out is None else out
