@@ -59,7 +59,7 @@ enum {
   TETRIS_E_COLUMNS = -3,     /* num_columns not built into this library */
   TETRIS_E_ROWS = -4,        /* num_rows outside [4, 59] */
   TETRIS_E_PIECES = -5,      /* bad piece list */
-  TETRIS_E_BATCH = -6,       /* B <= 0 or B * num_columns * word_bytes >= 2^31 */
+  TETRIS_E_BATCH = -6,       /* B <= 0 (tetris_hip_step: or B > 2^26 - 1 envs per call) */
   TETRIS_E_STREAM = -7,      /* replay stream given without cursor / length */
   TETRIS_E_STRIDE = -8       /* afterstate strides not multiples of 4 floats / too small */
 };

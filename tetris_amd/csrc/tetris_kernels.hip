@@ -74,6 +74,7 @@ __device__ __forceinline__ unsigned wave_sum(int value_bits, int v) {
 
 struct StepParams {
   void* cols;
+  void* plane[tet::kMaxCols];  // cols + c * B, precomputed so each plane base sits in SGPRs
   uint64_t* meta;
   const int32_t* action;   // NULL: built-in uniform random policy
   int32_t* action_out;     // optional: the action each env played
@@ -93,7 +94,19 @@ struct StepParams {
   SetTable tab;
 };
 
-// Everything one lane reads for one env, fetched one tile ahead of the compute.
+// Access element `byte_off / sizeof(T)` of a wave-uniform array through a 32-bit BYTE offset:
+// base stays in SGPRs and the lane offset is one shared VGPR (global_load/store saddr form)
+// instead of a 64-bit VGPR address per access.  Callers guarantee byte_off < 2^32.
+template <typename T>
+__device__ __forceinline__ T ld_off(const T* base, uint32_t byte_off) {
+  return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+template <typename T>
+__device__ __forceinline__ void st_off(T* base, uint32_t byte_off, T v) {
+  *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + byte_off) = v;
+}
+
+// Everything one lane reads for one env.
 template <typename W, int C>
 struct StepInputs {
   W col[C];
@@ -108,9 +121,9 @@ __device__ __forceinline__ void load_inputs(const StepParams& p, uint32_t i, Ste
   const W* cols = static_cast<const W*>(p.cols);
   const uint32_t ii = i < p.B ? i : 0;
 #pragma unroll
-  for (int c = 0; c < C; ++c) in.col[c] = cols[(uint32_t)c * p.B + ii];  // 32-bit offsets: saddr + voffset
-  in.meta = p.meta[ii];
-  in.action = p.action ? p.action[ii] : -1;
+  for (int c = 0; c < C; ++c) in.col[c] = ld_off(static_cast<const W*>(p.plane[c]), ii * (uint32_t)sizeof(W));
+  in.meta = ld_off(p.meta, ii * 8u);
+  in.action = p.action ? ld_off(p.action, ii * 4u) : -1;
   in.draw = -1;
   in.draw_reset = -1;
   in.cursor = 0;
@@ -122,7 +135,7 @@ __device__ __forceinline__ void load_inputs(const StepParams& p, uint32_t i, Ste
     in.draw_reset = p.stream[r1 * p.B + ii];
   }
   in.status = make_uint4(0, 0, 0, 0);
-  if (p.status) in.status = reinterpret_cast<const uint4*>(p.status)[i >> 6];  // this wave's counter slot (allocated per tile)
+  if (p.status) in.status = ld_off(reinterpret_cast<const uint4*>(p.status), (i >> 6) * 16u);  // this wave's slot
 }
 
 // One tile of 256 envs per workgroup.  (A persistent grid-stride variant that prefetches the
@@ -162,24 +175,24 @@ __global__ __launch_bounds__(kBlock, step_waves<W>()) void step_kernel(const Ste
                         kBlock, p.cfg, p.env_offset + i, in.draw, in.draw_reset, out);
     invalid = out.invalid;
     if (p.obs) {
-      float4* o4 = reinterpret_cast<float4*>(p.obs) + 2 * i;
-      o4[0] = make_float4(out.obs[0], out.obs[1], out.obs[2], out.obs[3]);
-      o4[1] = make_float4(out.obs[4], out.obs[5], out.obs[6], out.obs[7]);
+      float4* o4 = reinterpret_cast<float4*>(p.obs);
+      st_off(o4, i * 32u, make_float4(out.obs[0], out.obs[1], out.obs[2], out.obs[3]));
+      st_off(o4, i * 32u + 16u, make_float4(out.obs[4], out.obs[5], out.obs[6], out.obs[7]));
     }
     if (!invalid) {
 #pragma unroll
-      for (int c = 0; c < C; ++c) cols[(uint32_t)c * p.B + i] = in.col[c];
-      p.meta[i] = in.meta;
+      for (int c = 0; c < C; ++c) st_off(static_cast<W*>(p.plane[c]), i * (uint32_t)sizeof(W), in.col[c]);
+      st_off(p.meta, i * 8u, in.meta);
       done = out.done;
       lines = out.lines;
       if (p.stream) p.cursor[i] = in.cursor + 1 + ((out.done && p.cfg.auto_reset) ? 1 : 0);
     }
-    p.reward[i] = out.reward;
-    p.done[i] = (uint8_t)out.done;
-    p.lines[i] = (uint8_t)out.lines;
-    p.n_valid[i] = (uint8_t)out.n_valid;
-    if (p.piece_next) p.piece_next[i] = (uint8_t)out.piece;
-    if (p.action_out) p.action_out[i] = out.action;
+    st_off(p.reward, i * 4u, (int32_t)out.reward);
+    st_off(p.done, i, (uint8_t)out.done);
+    st_off(p.lines, i, (uint8_t)out.lines);
+    st_off(p.n_valid, i, (uint8_t)out.n_valid);
+    if (p.piece_next) st_off(p.piece_next, i, (uint8_t)out.piece);
+    if (p.action_out) st_off(p.action_out, i * 4u, (int32_t)out.action);
   }
   if (p.status) {
     const unsigned n_inv = wave_sum(1, invalid);
@@ -192,7 +205,7 @@ __global__ __launch_bounds__(kBlock, step_waves<W>()) void step_kernel(const Ste
       v.y += n_done;
       v.z += n_lines;
       v.w += n_steps;
-      reinterpret_cast<uint4*>(p.status)[i >> 6] = v;
+      st_off(reinterpret_cast<uint4*>(p.status), (i >> 6) * 16u, v);
     }
   }
 }
@@ -627,10 +640,12 @@ int tetris_hip_step(const TetrisDesc* desc, void* cols, uint64_t* meta, const in
   int rc = check_desc(desc);
   if (rc) return rc;
   if (!cols || !meta || !reward || !done || !lines || !n_valid_next) return TETRIS_E_NULL;
-  if (B <= 0 || B > 0x7FFFFFFF / (desc->num_columns * desc->word_bytes)) return TETRIS_E_BATCH;
+  if (B <= 0 || B > 0x7FFFFFFF / 32) return TETRIS_E_BATCH;  // every per-env byte offset (<= 32 B/env) fits 32 bits
   if (stream && (!cursor || stream_len <= 0)) return TETRIS_E_STREAM;
   StepParams p;
   p.cols = cols;
+  for (int c = 0; c < tet::kMaxCols; ++c)
+    p.plane[c] = static_cast<char*>(cols) + (size_t)(c < desc->num_columns ? c : 0) * (size_t)B * desc->word_bytes;
   p.meta = meta;
   p.action = action;
   p.action_out = action_out;
