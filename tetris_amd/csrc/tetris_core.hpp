@@ -300,7 +300,8 @@ TET_HD int clear_lines(W (&col)[C], const W (&pbits)[4], int* eroded_cells) {
 // once per run top.  Column transitions (state.py:206,219-220,242-243) below the column top
 // come in pairs, one entering and one leaving every hole run (the floor counts as filled, the
 // top cell is filled), so they are 2 * (number of run tops) -- the same u.
-template <typename W>
+// NCH > 0: the board has exactly NCH 12-row chunks (compile-time); NCH = 0: decide from R.
+template <typename W, int NCH = 0>
 TET_HD void col_own(W x, int hi, int R, const uint8_t* hole_lut, W& ho, int& nh, int& f1, int& f7) {
   ho = (W)(~x & lowmask<W>(hi));                   // holes (state.py:210-213)
   nh = popc(ho);
@@ -308,13 +309,14 @@ TET_HD void col_own(W x, int hi, int R, const uint8_t* hole_lut, W& ho, int& nh,
   if (!(TET_ABLATE & 16)) {
 #pragma unroll
     for (int k = 0; 12 * k < (int)(8 * sizeof(W)) - 1; ++k) {
-      if (k < 2 || 12 * k < R + 4) {  // rows beyond the stored ones are zero: entry 0 adds nothing
+      // rows beyond the stored ones are zero: entry 0 adds nothing, so extra chunks are harmless
+      if (NCH > 0 ? k < NCH : (k < 2 || 12 * k < R + 4)) {
         const uint32_t e = hole_lut[(uint32_t)(x >> (12 * k)) & 0x1FFFu];
         const int uk = (int)(e >> 5);
         u += uk;
         d7 += (int)(e & 31u);
-        if (12 * (k + 1) < (int)(8 * sizeof(W)) && 12 * (k + 1) < R + 4)  // uniform: rows above this chunk exist
-          d7 += uk * popc((W)(x >> (12 * (k + 1))));
+        const bool more = NCH > 0 ? k + 1 < NCH : (12 * (k + 1) < R + 4);  // rows above this chunk exist
+        if (12 * (k + 1) < (int)(8 * sizeof(W)) && more) d7 += uk * popc((W)(x >> (12 * (k + 1))));
       }
     }
   }
@@ -339,7 +341,7 @@ TET_HD int col_rowtrans(W x, W L, int hi, int hL, int nh_left) {
 // columns the wall side is cut at max(h, R).  Every maximal vertical run of k well cells adds
 // k(k+1)/2: summed per 12-row chunk through the wells table (entry = S | lead << 7 | trail << 11)
 // with a carry for runs that cross chunk borders -- no data-dependent loop.
-template <typename W>
+template <typename W, int NCH = 0>
 TET_HD int col_wells(W x, W L, W Rr, int hi, int R, bool left_wall, bool right_wall, const uint8_t* lut) {
   W w = (W)(~x & L & Rr);
   if (left_wall || right_wall) w = (W)(w & lowmask<W>(hi > R ? hi : R));
@@ -347,7 +349,7 @@ TET_HD int col_wells(W x, W L, W Rr, int hi, int R, bool left_wall, bool right_w
   int total = 0, carry = 0;
 #pragma unroll
   for (int k = 0; 12 * k < (int)(8 * sizeof(W)) - 1; ++k) {
-    if (k < 2 || 12 * k < R + 4) {  // rows beyond the stored ones hold no well cells
+    if (NCH > 0 ? k < NCH : (k < 2 || 12 * k < R + 4)) {  // rows beyond the stored ones hold no well cells
       const uint32_t e = wl[(uint32_t)(w >> (12 * k)) & 0xFFFu];
       const int lead = (int)((e >> 7) & 15u);
       total += (int)(e & 127u) + carry * lead;
@@ -358,7 +360,7 @@ TET_HD int col_wells(W x, W L, W Rr, int hi, int R, bool left_wall, bool right_w
 }
 
 // state.py:175-280.  out = f0,f1,f2,f4,f5,f7.
-template <typename W, int C>
+template <typename W, int C, int NCH = 0>
 TET_HD void board_features(const W (&col)[C], const int (&h)[C], int R, const uint8_t* hole_lut,
                            int& rows_with_holes, int& col_trans, int& holes, int& wells, int& row_trans,
                            int& hole_depth) {
@@ -375,14 +377,14 @@ TET_HD void board_features(const W (&col)[C], const int (&h)[C], int R, const ui
     const int hL = (i == 0) ? R : h[i - 1];       // state.py:179 wall height = num_rows
     W ho;
     int nh, d1, d7;
-    col_own<W>(col[i], h[i], R, hole_lut, ho, nh, d1, d7);
+    col_own<W, NCH>(col[i], h[i], R, hole_lut, ho, nh, d1, d7);
     f1 += d1;
     f2 += nh;
     f7 += d7;
     hole_rows |= ho;                              // state.py:215
     f5 += col_rowtrans<W>(col[i], L, h[i], hL, nh_left);
     nh_left = nh;
-    f4 += col_wells<W>(col[i], L, Rr, h[i], R, i == 0, i == C - 1, hole_lut);
+    f4 += col_wells<W, NCH>(col[i], L, Rr, h[i], R, i == 0, i == C - 1, hole_lut);
   }
   rows_with_holes = popc(hole_rows);  // state.py:274-275
   col_trans = f1;
@@ -393,11 +395,11 @@ TET_HD void board_features(const W (&col)[C], const int (&h)[C], int R, const ui
 }
 
 // state.py:97-107: the eight BCTS features as float32
-template <typename W, int C>
+template <typename W, int C, int NCH = 0>
 TET_HD void bcts_features(const W (&col)[C], const int (&h)[C], int R, const uint8_t* hole_lut, int anchor_row,
                           int H, int eroded_cells, int n_cleared, float (&f)[8]) {
   int f0, f1, f2, f4, f5, f7;
-  board_features<W, C>(col, h, R, hole_lut, f0, f1, f2, f4, f5, f7);
+  board_features<W, C, NCH>(col, h, R, hole_lut, f0, f1, f2, f4, f5, f7);
   f[0] = (float)f0;
   f[1] = (float)f1;
   f[2] = (float)f2;
@@ -769,7 +771,7 @@ TET_HD int policy_random(uint32_t key_policy, uint32_t env, int n_valid) {
 
 // `action` < 0 with use_policy: draw it with policy_random.  `draw` = replay piece for the
 // step draw (or -1: use the bag), `draw_reset` = replay piece for the reset draw (or -1).
-template <typename W, int C>
+template <typename W, int C, int NCH = 0>
 TET_HD void env_step(W (&col)[C], uint64_t& meta, int action, bool use_policy, const SetTable& tab,
                      const uint8_t* hole_lut, W* scratch, int sstride, const StepCfg& cfg, uint32_t env, int draw,
                      int draw_reset, StepOut& out) {
@@ -807,7 +809,7 @@ TET_HD void env_step(W (&col)[C], uint64_t& meta, int action, bool use_policy, c
 #pragma unroll
     for (int i = 0; i < 8; ++i) out.obs[i] = (float)h[i];
   } else
-  bcts_features<W, C>(col, h, R, hole_lut, a, oH, eroded, k, out.obs);  // game.py:91
+  bcts_features<W, C, NCH>(col, h, R, hole_lut, a, oH, eroded, k, out.obs);  // game.py:91
   if (cfg.has_direct_by) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) out.obs[i] *= cfg.direct_by[i];

@@ -141,7 +141,9 @@ __device__ __forceinline__ void load_inputs(const StepParams& p, uint32_t i, Ste
 // One tile of 256 envs per workgroup.  (A persistent grid-stride variant that prefetches the
 // next tile was measured and is slower: the kernel is bound by integer-VALU issue, not by
 // exposed memory latency, and the prefetch registers cost occupancy.)
-template <typename W, int C>
+// NCH = number of 12-row chunks of the stored board, fixed at compile time for the common
+// geometries (2: up to 24 stored rows, e.g. 10x20; 4: up to 48, e.g. 10x40), 0 = decide from R.
+template <typename W, int C, int NCH>
 __global__ __launch_bounds__(kBlock, step_waves<W>()) void step_kernel(const StepParams p) {
   __shared__ SetTable tab;
   __shared__ __attribute__((aligned(16))) uint8_t hole_lut[tet::kFeatureLutBytes];
@@ -171,8 +173,9 @@ __global__ __launch_bounds__(kBlock, step_waves<W>()) void step_kernel(const Ste
   int invalid = 0, done = 0, lines = 0;
   if (live) {
     tet::StepOut out;
-    tet::env_step<W, C>(in.col, in.meta, in.action, p.action == nullptr, tab, hole_lut, &lane_cols[0][threadIdx.x],
-                        kBlock, p.cfg, p.env_offset + i, in.draw, in.draw_reset, out);
+    tet::env_step<W, C, NCH>(in.col, in.meta, in.action, p.action == nullptr, tab, hole_lut,
+                             &lane_cols[0][threadIdx.x], kBlock, p.cfg, p.env_offset + i, in.draw, in.draw_reset,
+                             out);
     invalid = out.invalid;
     if (p.obs) {
       float4* o4 = reinterpret_cast<float4*>(p.obs);
@@ -526,7 +529,13 @@ int dispatch(const TetrisDesc* d, const P& p, hipStream_t s) {
 template <typename W, int C>
 struct LaunchStep {
   static void run(const StepParams& p, hipStream_t s) {
-    hipLaunchKernelGGL((step_kernel<W, C>), grid_for(p.B), dim3(kBlock), 0, s, p);
+    const int stored = p.cfg.R + 4;
+    if (sizeof(W) == 4 && stored <= 24)
+      hipLaunchKernelGGL((step_kernel<W, C, 2>), grid_for(p.B), dim3(kBlock), 0, s, p);
+    else if (sizeof(W) == 8 && stored > 36 && stored <= 48)
+      hipLaunchKernelGGL((step_kernel<W, C, 4>), grid_for(p.B), dim3(kBlock), 0, s, p);
+    else
+      hipLaunchKernelGGL((step_kernel<W, C, 0>), grid_for(p.B), dim3(kBlock), 0, s, p);
   }
 };
 template <typename W, int C>
