@@ -91,6 +91,9 @@ def main():
     ap.add_argument("--gather-every", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-obs", action="store_true", help="skip the observation output (uses 95 B / 175 B per env-step)")
+    ap.add_argument("--fuse", type=int, default=1,
+                    help="env-steps per kernel launch (tetris_hip_step_many: boards stay in registers between the "
+                         "fused steps, every step's outputs are still written); 1 = one launch per step (headline)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
 
@@ -122,16 +125,24 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    fuse = max(1, args.fuse)
+    if args.steps % fuse or args.warmup % fuse:
+        raise SystemExit("--steps and --warmup must be multiples of --fuse")
+    traj = [None]
+
     def one_step(t):
-        env.step()  # action = None: uniform random valid action drawn inside the step kernel
-        if world > 1 and (t + 1) % args.gather_every == 0:
+        if fuse == 1:
+            env.step()  # action = None: uniform random valid action drawn inside the step kernel
+        else:
+            traj[0] = env.step_many(fuse, out=traj[0])  # `fuse` steps per launch, trajectory buffers reused
+        if world > 1 and (t + 1) % max(1, args.gather_every // fuse) == 0:
             gather.gather_counters(env.totals())
 
-    for t in range(args.warmup):
+    for t in range(args.warmup // fuse):
         one_step(t)
     barrier()
     t0 = time.perf_counter()
-    for t in range(args.steps):
+    for t in range(args.steps // fuse):
         one_step(t)
     if world > 1:
         gather.gather_bits(env.done)  # the done/reset gather over RCCL
@@ -152,7 +163,7 @@ def main():
         s_ev, e_ev = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s_ev.record()
         for _ in range(n_per):
-            env.step()
+            one_step(-2)
         e_ev.record()
         torch.cuda.synchronize(dev)
         k_ms.append(s_ev.elapsed_time(e_ev) / n_per)
@@ -161,7 +172,7 @@ def main():
 
     if rank == 0:
         alg = algorithmic_bytes_per_env_step(args.columns, env.desc.word_bytes, not args.no_obs)
-        achieved = alg * B / (k_ms * 1e-3) / 1e9
+        achieved = alg * B * fuse / (k_ms * 1e-3) / 1e9
         out = {
             "metric": "env-steps/sec",
             "value": B * world * args.steps / dt,
@@ -178,13 +189,13 @@ def main():
             "config": {"workload": "%d envs/GPU x %d GPU, %dx%d board, pieces=%s, uniform random valid actions, "
                                    "in-kernel auto-reset, device bag seed 0" % (B, world, args.columns, args.rows,
                                                                                 args.pieces),
-                       "envs_per_gpu": B, "observation_output": not args.no_obs, "board": "%dx%d" % (args.columns, args.rows), "pieces": args.pieces,
+                       "envs_per_gpu": B, "observation_output": not args.no_obs, "env_steps_per_launch": fuse, "board": "%dx%d" % (args.columns, args.rows), "pieces": args.pieces,
                        "sharding": "env-index ranges, no data-path collective; RCCL gathers done counters every "
                                    "%d steps + done bitmask at the end" % args.gather_every},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None if args.no_obs else load_traffic(args.columns, args.rows, args.pieces, B),
-                         "kernel": "step_kernel", "kernel_ms": k_ms, "algorithmic_bytes_per_env_step": alg},
+                         "traffic": None if (args.no_obs or fuse > 1) else load_traffic(args.columns, args.rows, args.pieces, B),
+                         "kernel": "step_kernel" if fuse == 1 else "step_many_kernel (%d steps per launch)" % fuse, "kernel_ms": k_ms, "algorithmic_bytes_per_env_step": alg},
             "episodes": totals[1], "lines_cleared": totals[2],
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -142,6 +142,21 @@ int tetris_hip_step(const TetrisDesc* desc, void* cols, uint64_t* meta, const in
                     uint64_t step_idx, int64_t env_offset, int64_t B, void* hip_stream);
 
 /*
+ * K consecutive Tetris.step calls of every env in ONE launch, for policies that live in the
+ * kernel (policy 0: uniform random valid action; 1: greedy on `weights`, HOST pointer to 8
+ * floats).  Boards and meta stay in registers between the steps; every step's outputs go to
+ * trajectory buffers indexed [k][i] (k-major): action_out int32[K][B] (or NULL), obs
+ * float32[K][B][8] (or NULL), reward int32[K][B], done / lines / n_valid_next / piece_next
+ * uint8[K][B] (piece_next may be NULL).  Bit-identical to K calls of tetris_hip_step with
+ * action = NULL (policy 0) and step_idx = step_idx0 .. step_idx0 + K - 1.  K * B < 2^26.
+ */
+int tetris_hip_step_many(const TetrisDesc* desc, void* cols, uint64_t* meta, int32_t n_steps,
+                         int32_t policy, const float* weights, int32_t* action_out, float* obs,
+                         int32_t* reward, uint8_t* done, uint8_t* lines, uint8_t* n_valid_next,
+                         uint8_t* piece_next, uint32_t* status, int32_t auto_reset, uint64_t seed,
+                         uint64_t step_idx0, int64_t env_offset, int64_t B, void* hip_stream);
+
+/*
  * Tetris.get_after_states (game.py:67-80): BCTS features of every placement
  * of the current piece.
  *  feats     : float32, row k of env i at feats + i*env_stride + k*row_stride (strides in

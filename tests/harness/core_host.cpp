@@ -339,6 +339,82 @@ int tetris_host_rollouts(const TetrisDesc* desc, const void* cols_, const uint64
   });
 }
 
+int tetris_host_step_many(const TetrisDesc* desc, void* cols_, uint64_t* meta, int32_t n_steps, int32_t policy,
+                          const float* weights, int32_t* action_out, float* obs, int32_t* reward, uint8_t* done,
+                          uint8_t* lines, uint8_t* n_valid_next, uint8_t* piece_next, uint32_t* status,
+                          int32_t auto_reset, uint64_t seed, uint64_t step_idx0, int64_t env_offset, int64_t B,
+                          void* unused) {
+  (void)unused;
+  return dispatch(desc, [&](auto wt, auto ct) {
+    using W = decltype(wt);
+    constexpr int C = decltype(ct)::value;
+    tet::SetTable tab;
+    tet::build_table(desc, &tab);
+    float w[8];
+    for (int q = 0; q < 8; ++q) w[q] = weights ? weights[q] : 0.f;
+    tet::StepCfg cfg;
+    cfg.R = desc->num_rows;
+    cfg.n_pieces = desc->n_pieces;
+    cfg.auto_reset = auto_reset;
+    cfg.has_direct_by = desc->has_direct_by;
+    cfg.compute_obs = obs != nullptr;
+    for (int q = 0; q < 8; ++q) cfg.direct_by[q] = desc->direct_by[q];
+    W* cols = static_cast<W*>(cols_);
+    for (int64_t i = 0; i < B; ++i) {
+      W col[C];
+      for (int c = 0; c < C; ++c) col[c] = cols[(int64_t)c * B + i];
+      uint64_t m = meta[i];
+      for (int k = 0; k < n_steps; ++k) {
+        cfg.key_step = tet::hash_key(seed, (step_idx0 + k) * 4u + 0u);
+        cfg.key_policy = tet::hash_key(seed, (step_idx0 + k) * 4u + 3u);
+        int action = -1;
+        bool use_policy = true;
+        if (policy == 1) {
+          const uint64_t valid = tet::meta_mask(m);
+          float best = 0.f;
+          int best_row = -1;
+          tet::afterstates_env<W, C>(col, m, tab, kHoleLut, cfg.R, [&](int sk, int sc, float (&f)[8]) {
+            if ((valid >> (C * sk + sc)) & 1) {
+              const float v = tet::fitness_of(f, w);
+              const int row = tet::row_of_slot<C>(valid, sk, sc);
+              if (best_row < 0 || v > best || (v == best && row < best_row)) {
+                best = v;
+                best_row = row;
+              }
+            }
+          });
+          action = best_row;
+          use_policy = false;
+        }
+        W scratch[C];
+        tet::StepOut out;
+        tet::env_step<W, C>(col, m, action, use_policy, tab, kHoleLut, scratch, 1, cfg, (uint32_t)(env_offset + i),
+                            -1, -1, out);
+        const int64_t e = (int64_t)k * B + i;
+        if (obs)
+          for (int q = 0; q < 8; ++q) obs[e * 8 + q] = out.obs[q];
+        reward[e] = out.reward;
+        done[e] = (uint8_t)out.done;
+        lines[e] = (uint8_t)out.lines;
+        n_valid_next[e] = (uint8_t)out.n_valid;
+        if (piece_next) piece_next[e] = (uint8_t)out.piece;
+        if (action_out) action_out[e] = out.action;
+        if (status) {
+          uint32_t* slot = status + (i >> 6) * 4;
+          slot[TETRIS_STATUS_INVALID] += out.invalid;
+          if (!out.invalid) {
+            slot[TETRIS_STATUS_EPISODES] += out.done;
+            slot[TETRIS_STATUS_LINES] += out.lines;
+            slot[TETRIS_STATUS_STEPS] += 1;
+          }
+        }
+      }
+      for (int c = 0; c < C; ++c) cols[(int64_t)c * B + i] = col[c];
+      meta[i] = m;
+    }
+  });
+}
+
 int tetris_host_version(void) { return TETRIS_HIP_ABI_VERSION; }
 
 int64_t tetris_host_status_words(int64_t B) { return B <= 0 ? 0 : 4 * (((B + 255) / 256) * 4); }

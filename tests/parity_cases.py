@@ -346,3 +346,38 @@ def rollouts(device, orc, B=96):
             vals = np.unique(got[~np.isnan(got)])
             assert len(vals) > 2, vals  # deaths (-1 in the mean) and survivals both occur
         assert torch.equal(env.cols, before[0]) and torch.equal(env.meta, before[1])  # envs untouched
+
+
+def step_many_equals_steps(device, orc, B=700):
+    """tetris_hip_step_many(K) == K launches of tetris_hip_step (random policy), and the greedy
+    variant against step(greedy_actions()); also checked against the oracle."""
+    from tetris_amd import VecTetris
+    for rows, pieces in ((20, "default"), (40, "standard7")):
+        a = VecTetris(10, rows, B, device=device, pieces=pieces, auto_reset=True, seed=13)
+        b = VecTetris(10, rows, B, device=device, pieces=pieces, auto_reset=True, seed=13)
+        ref = orc.OracleVecEnv(10, rows, B, pieces=pieces, auto_reset=True, seed=13, nthreads=0)
+        out = None
+        for rep in range(4):
+            K = 7
+            out = a.step_many(K, out=out)
+            for k in range(K):
+                obs, rew, done, lines = b.step()
+                o_obs, o_rew, o_done, o_lines, n_bad = ref.step()
+                assert torch.equal(out["obs"][k], obs) and torch.equal(out["reward"][k], rew)
+                assert torch.equal(out["done"][k], done) and torch.equal(out["lines"][k], lines)
+                assert torch.equal(out["action"][k], b.action) and torch.equal(out["n_valid"][k], b.n_valid)
+                assert torch.equal(out["piece"][k], b.piece)
+                np.testing.assert_array_equal(obs.cpu().numpy(), o_obs)
+                np.testing.assert_array_equal(rew.cpu().numpy(), o_rew)
+            assert torch.equal(a.cols, b.cols) and torch.equal(a.meta, b.meta)
+            assert a.stats() == b.stats() and a.step_idx == b.step_idx
+            np.testing.assert_array_equal(a.boards().cpu().numpy(), ref.cells)
+    # greedy policy fused vs unfused
+    a = VecTetris(10, 20, 200, device=device, pieces="standard7", auto_reset=True, seed=2)
+    b = VecTetris(10, 20, 200, device=device, pieces="standard7", auto_reset=True, seed=2)
+    out = a.step_many(12, policy="greedy")
+    for k in range(12):
+        ba, _ = b.greedy_actions()
+        obs, rew, done, lines = b.step(ba.clone())
+        assert torch.equal(out["action"][k], ba) and torch.equal(out["obs"][k], obs) and torch.equal(out["done"][k], done)
+    assert torch.equal(a.cols, b.cols) and torch.equal(a.meta, b.meta)

@@ -105,3 +105,7 @@ def test_integration_md_stub_runs():
 
 def test_rollouts(orc):
     pc.rollouts(DEV, orc)
+
+
+def test_step_many_equals_steps(orc):
+    pc.step_many_equals_steps(DEV, orc)

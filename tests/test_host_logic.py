@@ -55,3 +55,7 @@ def test_greedy_policy(host_backend, orc, golden_dir):
 
 def test_rollouts(host_backend, orc):
     pc.rollouts(DEV, orc)
+
+
+def test_step_many_equals_steps(host_backend, orc):
+    pc.step_many_equals_steps(DEV, orc)

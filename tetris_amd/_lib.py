@@ -44,6 +44,8 @@ SIGNATURES = {
     "tetris_hip_reset": [_dp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _u64, _u64, _i64, _i64, _vp],
     "tetris_hip_step": [_dp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _u64, _u64,
                         _i64, _i64, _vp],
+    "tetris_hip_step_many": [_dp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _u64, _u64,
+                             _i64, _i64, _vp],
     "tetris_hip_afterstates": [_dp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp],
     "tetris_hip_policy_greedy": [_dp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
     "tetris_hip_rollouts": [_dp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _u64, _u64, _i64, _i64, _vp],

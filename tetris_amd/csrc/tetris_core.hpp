@@ -115,8 +115,8 @@ TET_HD uint32_t mix32(uint32_t x) {
   x ^= x >> 16;
   return x;
 }
-// env-independent part: computed once per launch on the host
-inline uint32_t hash_key(uint64_t seed, uint64_t counter) {
+// env-independent part: computed once per launch on the host (per step inside step_many)
+TET_HD uint32_t hash_key(uint64_t seed, uint64_t counter) {
   uint32_t k = mix32((uint32_t)seed ^ 0x9E3779B9U);
   k = mix32(k ^ (uint32_t)(seed >> 32));
   k = mix32(k ^ (uint32_t)counter);

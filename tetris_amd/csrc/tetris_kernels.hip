@@ -213,6 +213,99 @@ __global__ __launch_bounds__(kBlock, step_waves<W>()) void step_kernel(const Ste
   }
 }
 
+struct StepManyParams {
+  StepParams one;        // pointers of step 0; per-step outputs advance by B elements per step
+  int32_t n_steps;
+  int32_t policy;        // 0 uniform random, 1 greedy on w
+  uint64_t seed;
+  uint64_t step_idx0;
+  float w[8];
+};
+
+// K consecutive env-steps of every env in ONE launch, for policies that live in the kernel
+// (uniform random / greedy linear): the board and meta stay in registers between steps, every
+// step's outputs are written to trajectory buffers [K][B]...; bit-identical to K launches of
+// step_kernel with step_idx0, step_idx0 + 1, ...  (the per-step keys are re-derived on device).
+template <typename W, int C, int NCH, int POLICY>
+__global__ __launch_bounds__(kBlock, POLICY == 0 ? step_waves<W>() : 1) void step_many_kernel(const StepManyParams q) {
+  const StepParams& p = q.one;
+  __shared__ SetTable tab;
+  __shared__ __attribute__((aligned(16))) uint8_t hole_lut[tet::kFeatureLutBytes];
+  __shared__ W lane_cols[C][kBlock];
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  const bool live = i < p.B;
+  StepInputs<W, C> in;
+  load_inputs<W, C>(p, i, in);
+  stage_hole_lut(hole_lut);
+  stage_table(tab, p.tab);
+  unsigned n_inv = 0, n_done = 0, n_lines = 0, n_steps = 0;
+  StepCfg cfg = p.cfg;
+#pragma unroll 1
+  for (int k = 0; k < q.n_steps; ++k) {
+    cfg.key_step = tet::hash_key(q.seed, (q.step_idx0 + (uint64_t)k) * 4u + 0u);
+    cfg.key_policy = tet::hash_key(q.seed, (q.step_idx0 + (uint64_t)k) * 4u + 3u);
+    int invalid = 0, done = 0, lines = 0;
+    if (live) {
+      int action = -1;
+      bool use_policy = true;
+      if (POLICY == 1) {  // greedy: first non-terminal action of maximal fitness
+        const uint64_t valid = tet::meta_mask(in.meta);
+        float best = 0.f;
+        int best_row = -1;
+        tet::afterstates_env<W, C>(in.col, in.meta, tab, hole_lut, cfg.R, [&](int sk, int sc, float (&f)[8]) {
+          if ((valid >> (C * sk + sc)) & 1) {
+            const float v = tet::fitness_of(f, q.w);
+            const int row = tet::row_of_slot<C>(valid, sk, sc);
+            if (best_row < 0 || v > best || (v == best && row < best_row)) {
+              best = v;
+              best_row = row;
+            }
+          }
+        });
+        action = best_row;
+        use_policy = false;
+      }
+      tet::StepOut out;
+      tet::env_step<W, C, NCH>(in.col, in.meta, action, use_policy, tab, hole_lut, &lane_cols[0][threadIdx.x], kBlock,
+                               cfg, p.env_offset + i, -1, -1, out);
+      invalid = out.invalid;
+      const uint32_t e = (uint32_t)k * p.B + i;  // element index in the [K][B] trajectory buffers
+      if (p.obs) {
+        float4* o4 = reinterpret_cast<float4*>(p.obs);
+        st_off(o4, e * 32u, make_float4(out.obs[0], out.obs[1], out.obs[2], out.obs[3]));
+        st_off(o4, e * 32u + 16u, make_float4(out.obs[4], out.obs[5], out.obs[6], out.obs[7]));
+      }
+      if (!invalid) {
+        done = out.done;
+        lines = out.lines;
+      }
+      st_off(p.reward, e * 4u, (int32_t)out.reward);
+      st_off(p.done, e, (uint8_t)out.done);
+      st_off(p.lines, e, (uint8_t)out.lines);
+      st_off(p.n_valid, e, (uint8_t)out.n_valid);
+      if (p.piece_next) st_off(p.piece_next, e, (uint8_t)out.piece);
+      if (p.action_out) st_off(p.action_out, e * 4u, (int32_t)out.action);
+    }
+    n_inv += wave_sum(1, invalid);
+    n_done += wave_sum(1, done);
+    n_lines += wave_sum(3, lines);
+    n_steps += wave_sum(1, (live && !invalid) ? 1 : 0);
+  }
+  if (live) {
+#pragma unroll
+    for (int c = 0; c < C; ++c) st_off(static_cast<W*>(p.plane[c]), i * (uint32_t)sizeof(W), in.col[c]);
+    st_off(p.meta, i * 8u, in.meta);
+  }
+  if (p.status && (threadIdx.x & 63) == 0) {
+    uint4 v = in.status;
+    v.x += n_inv;
+    v.y += n_done;
+    v.z += n_lines;
+    v.w += n_steps;
+    st_off(reinterpret_cast<uint4*>(p.status), (i >> 6) * 16u, v);
+  }
+}
+
 struct ResetParams {
   void* cols;
   uint64_t* meta;
@@ -539,6 +632,20 @@ struct LaunchStep {
   }
 };
 template <typename W, int C>
+struct LaunchStepMany {
+  static void run(const StepManyParams& q, hipStream_t s) {
+    const int stored = q.one.cfg.R + 4;
+    if (q.policy == 1)
+      hipLaunchKernelGGL((step_many_kernel<W, C, 0, 1>), grid_for(q.one.B), dim3(kBlock), 0, s, q);
+    else if (sizeof(W) == 4 && stored <= 24)
+      hipLaunchKernelGGL((step_many_kernel<W, C, 2, 0>), grid_for(q.one.B), dim3(kBlock), 0, s, q);
+    else if (sizeof(W) == 8 && stored > 36 && stored <= 48)
+      hipLaunchKernelGGL((step_many_kernel<W, C, 4, 0>), grid_for(q.one.B), dim3(kBlock), 0, s, q);
+    else
+      hipLaunchKernelGGL((step_many_kernel<W, C, 0, 0>), grid_for(q.one.B), dim3(kBlock), 0, s, q);
+  }
+};
+template <typename W, int C>
 struct LaunchReset {
   static void run(const ResetParams& p, hipStream_t s) {
     hipLaunchKernelGGL((reset_kernel<W, C>), grid_for(p.B), dim3(kBlock), 0, s, p);
@@ -641,17 +748,53 @@ int tetris_hip_reset(const TetrisDesc* desc, void* cols, uint64_t* meta, const u
   return dispatch<LaunchReset>(desc, p, (hipStream_t)hip_stream);
 }
 
+static int fill_step_params(StepParams& p, const TetrisDesc* desc, void* cols, uint64_t* meta, const int32_t* action,
+                            int32_t* action_out, const uint8_t* stream, int32_t* cursor, int64_t stream_len,
+                            float* obs, int32_t* reward, uint8_t* done, uint8_t* lines, uint8_t* n_valid_next,
+                            uint8_t* piece_next, uint32_t* status, int32_t auto_reset, uint64_t seed,
+                            uint64_t step_idx, int64_t env_offset, int64_t B, int64_t max_elems);
+
+int tetris_hip_step_many(const TetrisDesc* desc, void* cols, uint64_t* meta, int32_t n_steps, int32_t policy,
+                         const float* weights, int32_t* action_out, float* obs, int32_t* reward, uint8_t* done,
+                         uint8_t* lines, uint8_t* n_valid_next, uint8_t* piece_next, uint32_t* status,
+                         int32_t auto_reset, uint64_t seed, uint64_t step_idx0, int64_t env_offset, int64_t B,
+                         void* hip_stream) {
+  if (n_steps < 1 || policy < 0 || policy > 1 || (policy == 1 && !weights)) return TETRIS_E_BATCH;
+  StepManyParams q;
+  int rc = fill_step_params(q.one, desc, cols, meta, nullptr, action_out, nullptr, nullptr, 0, obs, reward, done,
+                            lines, n_valid_next, piece_next, status, auto_reset, seed, step_idx0, env_offset, B,
+                            (int64_t)B * n_steps);
+  if (rc) return rc;
+  q.n_steps = n_steps;
+  q.policy = policy;
+  q.seed = seed;
+  q.step_idx0 = step_idx0;
+  for (int i = 0; i < 8; ++i) q.w[i] = weights ? weights[i] : 0.f;
+  return dispatch<LaunchStepMany>(desc, q, (hipStream_t)hip_stream);
+}
+
 int tetris_hip_step(const TetrisDesc* desc, void* cols, uint64_t* meta, const int32_t* action, int32_t* action_out,
                     const uint8_t* stream, int32_t* cursor, int64_t stream_len, float* obs, int32_t* reward,
                     uint8_t* done, uint8_t* lines, uint8_t* n_valid_next, uint8_t* piece_next, uint32_t* status,
                     int32_t auto_reset, uint64_t seed, uint64_t step_idx, int64_t env_offset, int64_t B,
                     void* hip_stream) {
+  StepParams p;
+  int rc = fill_step_params(p, desc, cols, meta, action, action_out, stream, cursor, stream_len, obs, reward, done,
+                            lines, n_valid_next, piece_next, status, auto_reset, seed, step_idx, env_offset, B, B);
+  if (rc) return rc;
+  return dispatch<LaunchStep>(desc, p, (hipStream_t)hip_stream);
+}
+
+static int fill_step_params(StepParams& p, const TetrisDesc* desc, void* cols, uint64_t* meta, const int32_t* action,
+                            int32_t* action_out, const uint8_t* stream, int32_t* cursor, int64_t stream_len,
+                            float* obs, int32_t* reward, uint8_t* done, uint8_t* lines, uint8_t* n_valid_next,
+                            uint8_t* piece_next, uint32_t* status, int32_t auto_reset, uint64_t seed,
+                            uint64_t step_idx, int64_t env_offset, int64_t B, int64_t max_elems) {
   int rc = check_desc(desc);
   if (rc) return rc;
   if (!cols || !meta || !reward || !done || !lines || !n_valid_next) return TETRIS_E_NULL;
-  if (B <= 0 || B > 0x7FFFFFFF / 32) return TETRIS_E_BATCH;  // every per-env byte offset (<= 32 B/env) fits 32 bits
+  if (B <= 0 || max_elems > 0x7FFFFFFF / 32) return TETRIS_E_BATCH;  // every byte offset (<= 32 B/element) fits 32 bits
   if (stream && (!cursor || stream_len <= 0)) return TETRIS_E_STREAM;
-  StepParams p;
   p.cols = cols;
   for (int c = 0; c < tet::kMaxCols; ++c)
     p.plane[c] = static_cast<char*>(cols) + (size_t)(c < desc->num_columns ? c : 0) * (size_t)B * desc->word_bytes;
@@ -679,7 +822,7 @@ int tetris_hip_step(const TetrisDesc* desc, void* cols, uint64_t* meta, const in
   p.cfg.has_direct_by = desc->has_direct_by;
   for (int i = 0; i < 8; ++i) p.cfg.direct_by[i] = desc->direct_by[i];
   build_table(desc, &p.tab);
-  return dispatch<LaunchStep>(desc, p, (hipStream_t)hip_stream);
+  return TETRIS_OK;
 }
 
 int tetris_hip_afterstates(const TetrisDesc* desc, const void* cols, const uint64_t* meta, float* feats,

@@ -192,6 +192,39 @@ class VecTetris:
         self.step_idx += 1
         return self.obs, self.reward, self.done, self.lines
 
+    def step_many(self, n_steps, policy="random", weights=None, out=None):
+        """``n_steps`` consecutive steps in ONE kernel launch with an in-kernel policy ("random":
+        uniform valid action; "greedy": linear fitness on ``weights``): boards stay in registers
+        between steps, every step's outputs are written.  Returns a dict of trajectory tensors
+        ``obs [K,B,8] f32, reward [K,B] i32, done [K,B] bool, lines [K,B] u8, action [K,B] i32,
+        n_valid [K,B] u8, piece [K,B] u8``; with policy "random" it is bit-identical to
+        ``n_steps`` calls of ``step()``.  Pass the previous result as ``out`` to reuse buffers."""
+        K, B, dev = int(n_steps), self.batch_size, self.device
+        pol = {"random": 0, "greedy": 1}[policy]
+        if self._stream is not None:
+            raise ValueError("step_many draws pieces from the device bag (no replay stream)")
+        if out is None or out["reward"].shape[0] != K:
+            out = dict(obs=torch.zeros((K, B, 8), dtype=torch.float32, device=dev),
+                       reward=torch.empty((K, B), dtype=torch.int32, device=dev),
+                       _done=torch.empty((K, B), dtype=torch.uint8, device=dev),
+                       lines=torch.empty((K, B), dtype=torch.uint8, device=dev),
+                       action=torch.empty((K, B), dtype=torch.int32, device=dev),
+                       n_valid=torch.empty((K, B), dtype=torch.uint8, device=dev),
+                       piece=torch.empty((K, B), dtype=torch.uint8, device=dev))
+            out["done"] = out["_done"].view(torch.bool)
+        w = (ctypes.c_float * 8)(*(self.BCTS_WEIGHTS if weights is None else [float(x) for x in weights]))
+        rc = self._lib.step_many(ctypes.byref(self.desc), _ptr(self.cols), _ptr(self.meta), K, pol, w,
+                                 _ptr(out["action"]), _ptr(out["obs"]) if self.compute_obs else None,
+                                 _ptr(out["reward"]), _ptr(out["_done"]), _ptr(out["lines"]), _ptr(out["n_valid"]),
+                                 _ptr(out["piece"]), _ptr(self.status), int(self.auto_reset), self.seed,
+                                 self.step_idx, self.env_offset, B, self._hip_stream())
+        self._lib.check(rc, "tetris_hip_step_many")
+        self.step_idx += K
+        # the per-step views keep describing the latest step
+        self.n_valid.copy_(out["n_valid"][K - 1])
+        self.piece.copy_(out["piece"][K - 1])
+        return out
+
     BCTS_WEIGHTS = (-24.04, -19.77, -13.08, -12.63, -10.49, -9.22, 6.6, -1.61)  # game.py:111-118
 
     def greedy_actions(self, weights=None, include_fitness=False):
