@@ -161,7 +161,7 @@ void after_impl(const TetrisDesc* desc, const void* cols_, const uint64_t* meta,
       const int s = C * sk + sc;
       // cross-checks (test harness only): (1) the incremental features against the full
       // evaluation of the same placement, (2) the cached mask against the direct terminal test
-      const tet::Orient o = tet::unpack_orient(tab.orient[piece][sk][0]);
+      const tet::Orient o = tet::unpack_orient(tab.orient[piece][sk].desc);
       W nb[C];
       W pbits[4];
       int nh[C];

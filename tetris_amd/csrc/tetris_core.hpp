@@ -176,17 +176,24 @@ TET_HD int bag_draw(uint32_t& bag, int n_pieces, uint32_t r16) {
 }
 
 // ---- per-set table staged in LDS -------------------------------------------
-// orient[p][L*2+o][0]  packed Orient descriptor (above)
-//                  [1]  valid_mask: four 6-bit shifts into the level word for the real
-//                       thresholds (bits 0-23); bit 24 vertical Straight; bit 25 relaxed
-//                       thresholds unconstrained
-//                  [2]  valid_mask: four 6-bit shifts for the thresholds relaxed by one row
-//                  [3]  valid_mask rescue rows: for t in {1,2} (board rows R-3+t) at 5t-5:
-//                       has | j0<<1 | j1<<3
+// One entry per (piece of the set, orientation slot k = 2L + o).  Every valid_mask field has a
+// whole word to itself on purpose: the kernels are integer-VALU bound while the LDS pipe idles,
+// so fields are fetched ready to use (wide LDS reads) instead of being shifted out of packed words.
+struct OrientEntry {
+  uint32_t desc;        // packed Orient descriptor (above)
+  uint32_t sh1[4];      // shifts into the level word for the real thresholds
+  uint32_t sh2[4];      // ... for the thresholds relaxed by one row
+  uint32_t resc[2][3];  // rescue rows t = 1, 2 (board rows R-3+t): has, j0, j1
+  uint32_t vert4;       // vertical Straight
+  uint32_t relax_free;  // relaxed thresholds unconstrained
+};
+
 struct SetTable {
-  uint32_t orient[kMaxPieces][4][4];
+  OrientEntry orient[kMaxPieces][4];
   uint64_t fullmask[kMaxPieces];   // all existing placements (every one valid)
 };
+
+TET_HD uint32_t tab_u8(uint32_t f) { return f; }
 
 // feature tables (tools/gen_hole_lut.py), staged in LDS by the kernels as ONE 16 KiB block:
 // bytes [0, 8192): hole-depth table (uint8, 13-bit index); bytes [8192, 16384): wells table
@@ -429,8 +436,8 @@ TET_HD void bcts_features(const W (&col)[C], const int (&h)[C], int R, const uin
 //  * e >= 2 can only be rescued when H = 4 (vertical Straight): rows R-2 and R-1 must
 //    both miss exactly column c.
 template <typename W, int C>
-TET_HD uint64_t valid_mask(const W (&col)[C], const int (&h)[C], const uint32_t (&tab)[4][4],
-                           uint64_t fullmask, int R) {
+TET_HD uint64_t valid_mask(const W (&col)[C], const int (&h)[C], const OrientEntry (&tab)[4], uint64_t fullmask,
+                           int R) {
   static_assert(C <= 10, "missing-cell rows are packed 3 bits per column into 32 bits");
   uint32_t P[3] = {0u, 0u, 0u};
   uint32_t Fall = 0;
@@ -466,30 +473,29 @@ TET_HD uint64_t valid_mask(const W (&col)[C], const int (&h)[C], const uint32_t 
   uint64_t mask = 0;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    const uint32_t w1 = tab[k][1], w2 = tab[k][2], rw = tab[k][3];
+    const OrientEntry& e = tab[k];
     uint32_t i1 = 0, i2 = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      i1 |= (uint32_t)(BB >> ((w1 >> (6 * j)) & 63u));
-      i2 |= (uint32_t)(BB >> ((w2 >> (6 * j)) & 63u));
+      i1 |= (uint32_t)(BB >> tab_u8(e.sh1[j]));
+      i2 |= (uint32_t)(BB >> tab_u8(e.sh2[j]));
     }
-    if ((w1 >> 25) & 1u) i2 = 0;
+    if (tab_u8(e.relax_free)) i2 = 0;
     // rescue by one cleared row (e = 1)
     uint32_t r1 = 0;
 #pragma unroll
     for (int t = 1; t < 3; ++t) {
-      const uint32_t f = rw >> (5 * (t - 1));
-      const int j0 = (f >> 1) & 3, j1 = (f >> 3) & 3;
+      const int j0 = (int)tab_u8(e.resc[t - 1][1]), j1 = (int)tab_u8(e.resc[t - 1][2]);
       int c0 = hi[t] - j1;
       c0 = c0 > 0 ? c0 : 0;
       int len = lo[t] - j0 + 1 - c0;
       len = len > 0 ? len : 0;
       len = len < 16 ? len : 16;
       const uint32_t iv = ((1u << len) - 1u) << c0;
-      r1 |= (f & 1u) ? iv : 0u;
+      r1 |= tab_u8(e.resc[t - 1][0]) ? iv : 0u;
     }
     uint32_t r2 = 0;
-    if ((w1 >> 24) & 1u) {  // vertical Straight: any of its three lower rows / both of R-2, R-1
+    if (tab_u8(e.vert4)) {  // vertical Straight: any of its three lower rows / both of R-2, R-1
       r1 = single[0] | single[1] | single[2];
       r2 = single[1] & single[2];
     }
@@ -613,7 +619,7 @@ TET_HD void afterstates_env(const W (&col)[C], uint64_t meta, const SetTable& ta
   uint64_t slow = 0;  // placements that clear lines: evaluated in full below
 #pragma unroll 1
   for (int k = 0; k < 4; ++k) {
-    const Orient o = unpack_orient(tab.orient[piece][k][0]);
+    const Orient o = unpack_orient(tab.orient[piece][k].desc);
     if (!o.exists) continue;
     const bool u1 = TET_WAVE_ANY(o.w > 1), u2 = TET_WAVE_ANY(o.w > 2), u3 = TET_WAVE_ANY(o.w > 3);
 #pragma unroll
@@ -717,7 +723,7 @@ TET_HD void afterstates_env(const W (&col)[C], uint64_t meta, const SetTable& ta
     W pbits[4];
     int fh[C];
     const int sk = s / C, sc = s - sk * C;
-    const uint32_t od = tab.orient[piece][sk][0];
+    const uint32_t od = tab.orient[piece][sk].desc;
     const int aa = stamp_dynamic<W, C>(fb, h, sc, od, pbits);
     int eroded = 0;
     const int kk = clear_lines<W, C>(fb, pbits, &eroded);
@@ -796,7 +802,7 @@ TET_HD void env_step(W (&col)[C], uint64_t& meta, int action, bool use_policy, c
   // decode action -> (orientation field, left column): game.py:69,83
   int sk, c;
   slot_of_action<C>(mask, action, sk, c);
-  const uint32_t od = tab.orient[piece][sk][0];
+  const uint32_t od = tab.orient[piece][sk].desc;
   const int oH = (od >> 3) & 7;
 
   int h[C];

@@ -156,17 +156,22 @@ __global__ __launch_bounds__(kBlock, step_waves<W>()) void step_kernel(const Ste
   load_inputs<W, C>(p, i, in);
   {
     static_assert(tet::kFeatureLutBytes == kBlock * 64, "four 16-byte pieces of the tables per lane");
-    static_assert(sizeof(SetTable) / 4 <= kBlock, "one table word per lane");
     const uint4* lsrc = reinterpret_cast<const uint4*>(&kFeatureLut);
     const uint4 l0 = lsrc[threadIdx.x], l1 = lsrc[threadIdx.x + kBlock];
     const uint4 l2 = lsrc[threadIdx.x + 2 * kBlock], l3 = lsrc[threadIdx.x + 3 * kBlock];
+    constexpr int kTabWords = (int)(sizeof(SetTable) / 4), kTabPerLane = (kTabWords + kBlock - 1) / kBlock;
     const uint32_t* tsrc = reinterpret_cast<const uint32_t*>(&p.tab);
-    const uint32_t tw = threadIdx.x < sizeof(SetTable) / 4 ? tsrc[threadIdx.x] : 0u;
+    uint32_t tw[kTabPerLane];
+#pragma unroll
+    for (int q = 0; q < kTabPerLane; ++q)
+      tw[q] = (int)threadIdx.x + q * kBlock < kTabWords ? tsrc[threadIdx.x + q * kBlock] : 0u;
     reinterpret_cast<uint4*>(hole_lut)[threadIdx.x] = l0;
     reinterpret_cast<uint4*>(hole_lut)[threadIdx.x + kBlock] = l1;
     reinterpret_cast<uint4*>(hole_lut)[threadIdx.x + 2 * kBlock] = l2;
     reinterpret_cast<uint4*>(hole_lut)[threadIdx.x + 3 * kBlock] = l3;
-    if (threadIdx.x < sizeof(SetTable) / 4) reinterpret_cast<uint32_t*>(&tab)[threadIdx.x] = tw;
+#pragma unroll
+    for (int q = 0; q < kTabPerLane; ++q)
+      if ((int)threadIdx.x + q * kBlock < kTabWords) reinterpret_cast<uint32_t*>(&tab)[threadIdx.x + q * kBlock] = tw[q];
     __syncthreads();
   }
   W* cols = static_cast<W*>(p.cols);

@@ -58,36 +58,32 @@ inline int n_placements(int pid, int C) {
 // thresholds: footprint column j needs slack R - h >= need_j = H - b_j.  valid_mask keeps the
 // column sets B_l = {c : slack < l} in 16-bit fields of one 64-bit word; the shift
 // 16*(need_j - 1) + j lines column c + j of level need_j up with bit c.
-inline void pack_mask_words(const CatOrient& o, uint32_t* w1, uint32_t* w2, uint32_t* w3) {
+inline void pack_mask_fields(const CatOrient& o, OrientEntry* e) {
   int H = 0;
   for (int j = 0; j < o.w; ++j)
     if (o.b[j] + o.n[j] > H) H = o.b[j] + o.n[j];
-  uint32_t sh1[4], sh2[4];
   int first2 = -1;
+  uint8_t sh2[4];
   for (int j = 0; j < o.w; ++j) {
     const int need = H - o.b[j];
-    sh1[j] = (uint32_t)(16 * (need - 1) + j);
+    e->sh1[j] = (uint32_t)(16 * (need - 1) + j);
     if (need - 1 >= 1) {
-      sh2[j] = (uint32_t)(16 * (need - 2) + j);
+      sh2[j] = (uint8_t)(16 * (need - 2) + j);
       if (first2 < 0) first2 = j;
     } else {
       sh2[j] = 0xFFu;  // unconstrained once relaxed
     }
   }
   for (int j = o.w; j < 4; ++j) {  // absent columns repeat column 0's term (OR is idempotent)
-    sh1[j] = sh1[0];
+    e->sh1[j] = e->sh1[0];
     sh2[j] = 0xFFu;
   }
-  uint32_t a = 0, b = 0, r = 0;
-  for (int j = 0; j < 4; ++j) {
-    if (sh2[j] == 0xFFu) sh2[j] = first2 >= 0 ? sh2[first2] : 0u;
-    a |= sh1[j] << (6 * j);
-    b |= sh2[j] << (6 * j);
-  }
-  if (o.w == 1 && H == 4) a |= 1u << 24;
-  if (first2 < 0) a |= 1u << 25;
+  for (int j = 0; j < 4; ++j) e->sh2[j] = sh2[j] == 0xFFu ? (first2 >= 0 ? sh2[first2] : 0) : sh2[j];
+  e->vert4 = (o.w == 1 && H == 4) ? 1 : 0;
+  e->relax_free = first2 < 0 ? 1 : 0;
   for (int t = 1; t < 3; ++t) {  // board row R-3+t holds piece row rho when the anchor is R+1-H
     const int rho = t - 4 + H;
+    e->resc[t - 1][0] = e->resc[t - 1][1] = e->resc[t - 1][2] = 0;
     if (rho < 0 || rho > H - 2) continue;
     int j0 = -1, j1 = -1;
     for (int j = 0; j < o.w; ++j)
@@ -95,11 +91,10 @@ inline void pack_mask_words(const CatOrient& o, uint32_t* w1, uint32_t* w2, uint
         if (j0 < 0) j0 = j;
         j1 = j;
       }
-    r |= (1u | ((uint32_t)j0 << 1) | ((uint32_t)j1 << 3)) << (5 * (t - 1));
+    e->resc[t - 1][0] = 1;
+    e->resc[t - 1][1] = (uint32_t)j0;
+    e->resc[t - 1][2] = (uint32_t)j1;
   }
-  *w1 = a;
-  *w2 = b;
-  *w3 = r;
 }
 
 inline void build_table(const TetrisDesc* d, SetTable* t) {
@@ -110,9 +105,9 @@ inline void build_table(const TetrisDesc* d, SetTable* t) {
     uint64_t full = 0;
     for (int l = 0; l < 2; ++l)
       for (int oi = 0; oi < p.n_orient[l]; ++oi) {
-        uint32_t* e = t->orient[i][l * 2 + oi];
-        e[0] = pack_orient(p.o[l][oi]);
-        pack_mask_words(p.o[l][oi], &e[1], &e[2], &e[3]);
+        OrientEntry* e = &t->orient[i][l * 2 + oi];
+        e->desc = pack_orient(p.o[l][oi]);
+        pack_mask_fields(p.o[l][oi], e);
         for (int c = 0; c + p.o[l][oi].w <= C; ++c) full |= 1ull << (C * (2 * l + oi) + c);
       }
     t->fullmask[i] = full;

@@ -17,6 +17,12 @@ from tetris_amd import VecTetris  # noqa: E402
 
 masks = [int(x) for x in (sys.argv[1:] or ["0", "1", "2", "4", "8", "3", "15"])]
 extra = os.environ.get("ABL_FLAGS", "").split()
+per_mask_flags = {}
+for spec in os.environ.get("ABL_VARIANTS", "").split(";"):
+    # e.g. ABL_VARIANTS="100:-DTET_AFTER_WAVES=3;101:-DTET_SCRATCH_OR=0" (build variants keyed by pseudo-mask)
+    if ":" in spec:
+        k, v = spec.split(":", 1)
+        per_mask_flags[int(k)] = v.split()
 # a mask >= 1000 means: TET_STEP_WAVES = mask // 1000, TET_ABLATE = mask % 1000
 rows = int(os.environ.get("ABL_ROWS", "20"))
 pieces = os.environ.get("ABL_PIECES", "default")
@@ -25,7 +31,9 @@ libs = {}
 for m in masks:
     out = "/tmp/libtetris_abl_%d.so" % m
     subprocess.check_call([build._hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC",
-                           "-DTET_ABLATE=%d" % (m % 1000), "-DTET_STEP_WAVES=%d" % (m // 1000)] + extra +
+                           "-DTET_ABLATE=%d" % (0 if m in per_mask_flags else m % 1000),
+                           "-DTET_STEP_WAVES=%d" % (0 if m in per_mask_flags else m // 1000)] + extra +
+                          per_mask_flags.get(m, []) +
                           [src, "-o", out])
     libs[m] = _lib._Binding(ctypes.CDLL(out))
 
