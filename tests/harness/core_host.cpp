@@ -18,15 +18,11 @@
 namespace {
 
 struct alignas(16) FeatureLut {
-  uint8_t hole[tet::kHoleLutSize];
-  uint16_t wells[tet::kWellsLutEntries];
+  uint8_t bytes[tet::kFeatureLutBytes];
 };
 const FeatureLut kFeatureLutHost = {{
-#include "../../tetris_amd/csrc/tetris_hole_lut.inc"
-                                    },
-                                    {
-#include "../../tetris_amd/csrc/tetris_wells_lut.inc"
-                                    }};
+#include "../../tetris_amd/csrc/tetris_feature_lut.inc"
+}};
 const uint8_t* const kHoleLut = reinterpret_cast<const uint8_t*>(&kFeatureLutHost);
 
 template <typename W, int C>
@@ -417,7 +413,7 @@ int tetris_host_step_many(const TetrisDesc* desc, void* cols_, uint64_t* meta, i
 
 int tetris_host_version(void) { return TETRIS_HIP_ABI_VERSION; }
 
-int64_t tetris_host_status_words(int64_t B) { return B <= 0 ? 0 : 4 * (((B + 255) / 256) * 4); }
+int64_t tetris_host_status_words(int64_t B) { return B <= 0 ? 0 : 4 * (((B + 1023) / 1024) * 16); }
 
 int tetris_host_n_placements(int32_t catalogue_id, int32_t num_columns) {
   if (catalogue_id < 0 || catalogue_id >= TETRIS_N_CATALOGUE) return TETRIS_E_PIECES;

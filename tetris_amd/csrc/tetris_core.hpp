@@ -27,6 +27,25 @@
 
 // wave-uniform "does any active lane want this": lets code that only some pieces need be
 // skipped by the whole wavefront (one env per lane).  On the host build it is the lane itself.
+// Fence for the instruction scheduler between the columns of board_features: without it the
+// compiler hoists every table read of all ten columns to the top (hundreds of live registers on
+// u64 boards -> spills or one wave per SIMD); latency is hidden by the other waves anyway.
+#ifndef TET_FENCE_EVERY
+#define TET_FENCE_EVERY 2
+#endif
+#ifndef TET_FENCE_MASK
+#define TET_FENCE_MASK 1
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+#define TET_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+// materialise an accumulator here: stops the compiler from re-associating the per-column sums into
+// one reduction at the end of the loop, which keeps every table value it has read live until then
+#define TET_PIN(x) asm volatile("" : "+v"(x))
+#else
+#define TET_SCHED_FENCE() ((void)0)
+#define TET_PIN(x) ((void)0)
+#endif
+
 #if defined(__HIP_DEVICE_COMPILE__)
 #define TET_WAVE_ANY(x) (__ballot((x)) != 0ull)
 #else
@@ -195,12 +214,14 @@ struct SetTable {
 
 TET_HD uint32_t tab_u8(uint32_t f) { return f; }
 
-// feature tables (tools/gen_hole_lut.py), staged in LDS by the kernels as ONE 16 KiB block:
-// bytes [0, 8192): hole-depth table (uint8, 13-bit index); bytes [8192, 16384): wells table
-// (uint16, 12-bit index)
+// feature tables (tools/gen_feature_lut.py), staged in LDS by the kernels as ONE block of byte
+// tables, one per field so nothing has to be shifted or masked out of a packed entry:
+// hole_A, hole_u (13-bit index), wells_S, wells_lead, wells_trail (12-bit index)
 constexpr int kHoleLutSize = 1 << 13;
 constexpr int kWellsLutEntries = 1 << 12;
-constexpr int kFeatureLutBytes = kHoleLutSize + 2 * kWellsLutEntries;
+constexpr int kLutHoleA = 0, kLutHoleU = kHoleLutSize, kLutWellsS = 2 * kHoleLutSize;
+constexpr int kLutWellsLead = kLutWellsS + kWellsLutEntries, kLutWellsTrail = kLutWellsLead + kWellsLutEntries;
+constexpr int kFeatureLutBytes = kLutWellsTrail + kWellsLutEntries;
 
 // bit c -> bit 2c (c < 16)
 TET_HD uint32_t spread2(uint32_t x) {
@@ -302,26 +323,30 @@ TET_HD int clear_lines(W (&col)[C], const W (&pbits)[4], int* eroded_cells) {
 // ---- per-column pieces of state.py:175-280 (closed forms of SURVEY App. B) ------------
 // Part that depends on the column alone: holes, column transitions, hole depth.
 // Hole depth (state.py:200,216,239): the top hole of each vertical run counts the filled cells
-// above it.  12-row chunks through the table: entry = A | u << 5 with u the run tops inside
-// the chunk and A their filled cells above inside the chunk; the cells above the chunk count
-// once per run top.  Column transitions (state.py:206,219-220,242-243) below the column top
-// come in pairs, one entering and one leaving every hole run (the floor counts as filled, the
-// top cell is filled), so they are 2 * (number of run tops) -- the same u.
+// above it.  12-row chunks through the tables: u = the run tops inside the chunk, A = their
+// filled cells above inside the chunk; the cells above the chunk count once per run top.
+// Column transitions (state.py:206,219-220,242-243) below the column top come in pairs, one
+// entering and one leaving every hole run (the floor counts as filled, the top cell is filled),
+// so they are 2 * (number of run tops) -- the same u.
 // NCH > 0: the board has exactly NCH 12-row chunks (compile-time); NCH = 0: decide from R.
+// Columns hold no bits at or above row R + 4, so the top chunk of an NCH board needs no mask.
 template <typename W, int NCH = 0>
-TET_HD void col_own(W x, int hi, int R, const uint8_t* hole_lut, W& ho, int& nh, int& f1, int& f7) {
+TET_HD void col_own(W x, int hi, int R, const uint8_t* lut, W& ho, int& nh, int& f1, int& f7) {
   ho = (W)(~x & lowmask<W>(hi));                   // holes (state.py:210-213)
   nh = popc(ho);
+  const uint8_t* lut_a = lut + kLutHoleA;
+  const uint8_t* lut_u = lut + kLutHoleU;
   int d7 = 0, u = 0;
   if (!(TET_ABLATE & 16)) {
 #pragma unroll
     for (int k = 0; 12 * k < (int)(8 * sizeof(W)) - 1; ++k) {
       // rows beyond the stored ones are zero: entry 0 adds nothing, so extra chunks are harmless
       if (NCH > 0 ? k < NCH : (k < 2 || 12 * k < R + 4)) {
-        const uint32_t e = hole_lut[(uint32_t)(x >> (12 * k)) & 0x1FFFu];
-        const int uk = (int)(e >> 5);
+        const uint32_t up = (uint32_t)(x >> (12 * k));
+        const uint32_t idx = (NCH > 0 && k == NCH - 1) ? up : (up & 0x1FFFu);
+        const int uk = lut_u[idx];
         u += uk;
-        d7 += (int)(e & 31u);
+        d7 += lut_a[idx];
         const bool more = NCH > 0 ? k + 1 < NCH : (12 * (k + 1) < R + 4);  // rows above this chunk exist
         if (12 * (k + 1) < (int)(8 * sizeof(W)) && more) d7 += uk * popc((W)(x >> (12 * (k + 1))));
       }
@@ -346,21 +371,33 @@ TET_HD int col_rowtrans(W x, W L, int hi, int hL, int nh_left) {
 // min(hL, hR) count, with wall height R (state.py:179,258-261) -- neighbours have no cells at or
 // above their own height, so for inner columns the set is simply ~x & L & R, and for the edge
 // columns the wall side is cut at max(h, R).  Every maximal vertical run of k well cells adds
-// k(k+1)/2: summed per 12-row chunk through the wells table (entry = S | lead << 7 | trail << 11)
-// with a carry for runs that cross chunk borders -- no data-dependent loop.
+// k(k+1)/2: summed per 12-row chunk through the wells tables (S, lead, trail) with a carry for
+// runs that cross chunk borders -- no data-dependent loop.  (A full chunk has trail = lead = 12.)
 template <typename W, int NCH = 0>
 TET_HD int col_wells(W x, W L, W Rr, int hi, int R, bool left_wall, bool right_wall, const uint8_t* lut) {
   W w = (W)(~x & L & Rr);
   if (left_wall || right_wall) w = (W)(w & lowmask<W>(hi > R ? hi : R));
-  const uint16_t* wl = reinterpret_cast<const uint16_t*>(lut + kHoleLutSize);
+  const uint8_t* lut_s = lut + kLutWellsS;
+  const uint8_t* lut_lead = lut + kLutWellsLead;
+  const uint8_t* lut_trail = lut + kLutWellsTrail;
   int total = 0, carry = 0;
 #pragma unroll
   for (int k = 0; 12 * k < (int)(8 * sizeof(W)) - 1; ++k) {
     if (NCH > 0 ? k < NCH : (k < 2 || 12 * k < R + 4)) {  // rows beyond the stored ones hold no well cells
-      const uint32_t e = wl[(uint32_t)(w >> (12 * k)) & 0xFFFu];
-      const int lead = (int)((e >> 7) & 15u);
-      total += (int)(e & 127u) + carry * lead;
-      carry = (lead == 12) ? carry + 12 : (int)(e >> 11);
+      const uint32_t up = (uint32_t)(w >> (12 * k));
+      const uint32_t idx = (NCH > 0 && k == NCH - 1) ? up : (up & 0xFFFu);
+      const bool last = NCH > 0 && k == NCH - 1;
+      total += lut_s[idx];
+      if (k == 0) {
+        if (!last) carry = lut_trail[idx];
+      } else {
+        const int lead = lut_lead[idx];
+        total += carry * lead;
+        if (!last) {
+          const int trail = lut_trail[idx];  // read unconditionally: a select, not a branch around the load
+          carry = (lead == 12) ? carry + 12 : trail;
+        }
+      }
     }
   }
   return (TET_ABLATE & 32) ? 0 : total;
@@ -392,6 +429,14 @@ TET_HD void board_features(const W (&col)[C], const int (&h)[C], int R, const ui
     f5 += col_rowtrans<W>(col[i], L, h[i], hL, nh_left);
     nh_left = nh;
     f4 += col_wells<W, NCH>(col[i], L, Rr, h[i], R, i == 0, i == C - 1, hole_lut);
+    if (TET_FENCE_EVERY > 0 && i % TET_FENCE_EVERY == TET_FENCE_EVERY - 1 && i + 1 < C) {
+      TET_PIN(f1);
+      TET_PIN(f2);
+      TET_PIN(f4);
+      TET_PIN(f5);
+      TET_PIN(f7);
+      TET_SCHED_FENCE();
+    }
   }
   rows_with_holes = popc(hole_rows);  // state.py:274-275
   col_trans = f1;
@@ -501,6 +546,7 @@ TET_HD uint64_t valid_mask(const W (&col)[C], const int (&h)[C], const OrientEnt
     }
     const uint32_t v = (~i1 | (~(i2 & ~r2) & r1)) & cm;
     mask |= (uint64_t)v << (C * k);
+    if (TET_FENCE_MASK) TET_SCHED_FENCE();  // keep one orientation's table words live at a time
   }
   return mask & fullmask;
 }

@@ -29,22 +29,29 @@ constexpr int kBlock = 256;
 #define TET_STEP_WAVES 0
 #endif
 template <typename W>
-constexpr int step_waves() { return TET_STEP_WAVES ? TET_STEP_WAVES : (sizeof(W) == 4 ? 5 : 1); }
+constexpr int step_waves() { return TET_STEP_WAVES ? TET_STEP_WAVES : (sizeof(W) == 4 ? 5 : 3); }
+
+// envs per workgroup of the step kernel: the feature tables are staged once per workgroup, so a
+// larger tile amortises that L2 -> LDS traffic over more envs.  u32 boards: 512 (8 waves = 2 per
+// SIMD per workgroup, two workgroups per CU; measured 37.9 us against 40.0 us with 256; 320, 640
+// and 1024 are slower: uneven waves per SIMD / one workgroup per CU).  u64 boards keep 256 (their
+// ~136 VGPRs allow 3 waves per SIMD = three 256-env workgroups).
+#ifndef TET_STEP_BLOCK
+#define TET_STEP_BLOCK 0
+#endif
+template <typename W>
+constexpr int step_block() { return TET_STEP_BLOCK ? TET_STEP_BLOCK : (sizeof(W) == 4 ? 512 : 256); }
 
 // ---- kernels ------------------------------------------------------------------
 
-// feature tables (tools/gen_hole_lut.py): hole depth (8 KiB of uint8) followed by wells (8 KiB of
-// uint16), copied to LDS as one block by the kernels that compute features
+// feature tables (tools/gen_feature_lut.py): byte tables for hole depth and wells (28 KiB), copied
+// to LDS as one block by the kernels that compute features
 struct alignas(16) FeatureLut {
-  uint8_t hole[tet::kHoleLutSize];
-  uint16_t wells[tet::kWellsLutEntries];
+  uint8_t bytes[tet::kFeatureLutBytes];
 };
 __device__ const FeatureLut kFeatureLut = {{
-#include "tetris_hole_lut.inc"
-                                           },
-                                           {
-#include "tetris_wells_lut.inc"
-                                           }};
+#include "tetris_feature_lut.inc"
+}};
 static_assert(sizeof(FeatureLut) == tet::kFeatureLutBytes, "layout assumed by col_wells");
 
 __device__ __forceinline__ void stage_hole_lut(uint8_t* lds) {
@@ -144,7 +151,8 @@ __device__ __forceinline__ void load_inputs(const StepParams& p, uint32_t i, Ste
 // NCH = number of 12-row chunks of the stored board, fixed at compile time for the common
 // geometries (2: up to 24 stored rows, e.g. 10x20; 4: up to 48, e.g. 10x40), 0 = decide from R.
 template <typename W, int C, int NCH>
-__global__ __launch_bounds__(kBlock, step_waves<W>()) void step_kernel(const StepParams p) {
+__global__ __launch_bounds__(step_block<W>(), step_waves<W>()) void step_kernel(const StepParams p) {
+  constexpr int kBlock = step_block<W>();  // shadows the file-wide tile size inside this kernel
   __shared__ SetTable tab;
   __shared__ __attribute__((aligned(16))) uint8_t hole_lut[tet::kFeatureLutBytes];
   __shared__ W lane_cols[C][kBlock];  // per-lane scratch for the runtime-indexed stamp (bank = lane)
@@ -155,20 +163,24 @@ __global__ __launch_bounds__(kBlock, step_waves<W>()) void step_kernel(const Ste
   StepInputs<W, C> in;
   load_inputs<W, C>(p, i, in);
   {
-    static_assert(tet::kFeatureLutBytes == kBlock * 64, "four 16-byte pieces of the tables per lane");
+    constexpr int kLutVecs = tet::kFeatureLutBytes / 16, kLutPerLane = (kLutVecs + kBlock - 1) / kBlock;
     const uint4* lsrc = reinterpret_cast<const uint4*>(&kFeatureLut);
-    const uint4 l0 = lsrc[threadIdx.x], l1 = lsrc[threadIdx.x + kBlock];
-    const uint4 l2 = lsrc[threadIdx.x + 2 * kBlock], l3 = lsrc[threadIdx.x + 3 * kBlock];
+    uint4 lv[kLutPerLane];
+#pragma unroll
+    for (int q = 0; q < kLutPerLane; ++q) {  // (clamped, not predicated: keeps lv[] in registers)
+      const int t = (int)threadIdx.x + q * kBlock;
+      lv[q] = lsrc[kLutVecs % kBlock == 0 || t < kLutVecs ? t : kLutVecs - 1];
+    }
     constexpr int kTabWords = (int)(sizeof(SetTable) / 4), kTabPerLane = (kTabWords + kBlock - 1) / kBlock;
     const uint32_t* tsrc = reinterpret_cast<const uint32_t*>(&p.tab);
     uint32_t tw[kTabPerLane];
 #pragma unroll
     for (int q = 0; q < kTabPerLane; ++q)
       tw[q] = (int)threadIdx.x + q * kBlock < kTabWords ? tsrc[threadIdx.x + q * kBlock] : 0u;
-    reinterpret_cast<uint4*>(hole_lut)[threadIdx.x] = l0;
-    reinterpret_cast<uint4*>(hole_lut)[threadIdx.x + kBlock] = l1;
-    reinterpret_cast<uint4*>(hole_lut)[threadIdx.x + 2 * kBlock] = l2;
-    reinterpret_cast<uint4*>(hole_lut)[threadIdx.x + 3 * kBlock] = l3;
+#pragma unroll
+    for (int q = 0; q < kLutPerLane; ++q)
+      if (kLutVecs % kBlock == 0 || (int)threadIdx.x + q * kBlock < kLutVecs)
+        reinterpret_cast<uint4*>(hole_lut)[threadIdx.x + q * kBlock] = lv[q];
 #pragma unroll
     for (int q = 0; q < kTabPerLane; ++q)
       if ((int)threadIdx.x + q * kBlock < kTabWords) reinterpret_cast<uint32_t*>(&tab)[threadIdx.x + q * kBlock] = tw[q];
@@ -232,7 +244,8 @@ struct StepManyParams {
 // step's outputs are written to trajectory buffers [K][B]...; bit-identical to K launches of
 // step_kernel with step_idx0, step_idx0 + 1, ...  (the per-step keys are re-derived on device).
 template <typename W, int C, int NCH, int POLICY>
-__global__ __launch_bounds__(kBlock, POLICY == 0 ? step_waves<W>() : 1) void step_many_kernel(const StepManyParams q) {
+__global__ __launch_bounds__(step_block<W>(), POLICY == 0 ? step_waves<W>() : 1) void step_many_kernel(const StepManyParams q) {
+  constexpr int kBlock = step_block<W>();  // shadows the file-wide tile size inside this kernel
   const StepParams& p = q.one;
   __shared__ SetTable tab;
   __shared__ __attribute__((aligned(16))) uint8_t hole_lut[tet::kFeatureLutBytes];
@@ -607,6 +620,8 @@ __global__ __launch_bounds__(kBlock) void encode_kernel(const int8_t* __restrict
 // ---- dispatch on (word, C) -------------------------------------------------------
 
 inline dim3 grid_for(int64_t B) { return dim3((unsigned)((B + kBlock - 1) / kBlock)); }
+template <typename W>
+inline dim3 step_grid(int64_t B) { return dim3((unsigned)((B + step_block<W>() - 1) / step_block<W>())); }
 
 template <template <typename, int> class Launcher, typename P>
 int dispatch(const TetrisDesc* d, const P& p, hipStream_t s) {
@@ -629,11 +644,11 @@ struct LaunchStep {
   static void run(const StepParams& p, hipStream_t s) {
     const int stored = p.cfg.R + 4;
     if (sizeof(W) == 4 && stored <= 24)
-      hipLaunchKernelGGL((step_kernel<W, C, 2>), grid_for(p.B), dim3(kBlock), 0, s, p);
+      hipLaunchKernelGGL((step_kernel<W, C, 2>), step_grid<W>(p.B), dim3(step_block<W>()), 0, s, p);
     else if (sizeof(W) == 8 && stored > 36 && stored <= 48)
-      hipLaunchKernelGGL((step_kernel<W, C, 4>), grid_for(p.B), dim3(kBlock), 0, s, p);
+      hipLaunchKernelGGL((step_kernel<W, C, 4>), step_grid<W>(p.B), dim3(step_block<W>()), 0, s, p);
     else
-      hipLaunchKernelGGL((step_kernel<W, C, 0>), grid_for(p.B), dim3(kBlock), 0, s, p);
+      hipLaunchKernelGGL((step_kernel<W, C, 0>), step_grid<W>(p.B), dim3(step_block<W>()), 0, s, p);
   }
 };
 template <typename W, int C>
@@ -641,13 +656,13 @@ struct LaunchStepMany {
   static void run(const StepManyParams& q, hipStream_t s) {
     const int stored = q.one.cfg.R + 4;
     if (q.policy == 1)
-      hipLaunchKernelGGL((step_many_kernel<W, C, 0, 1>), grid_for(q.one.B), dim3(kBlock), 0, s, q);
+      hipLaunchKernelGGL((step_many_kernel<W, C, 0, 1>), step_grid<W>(q.one.B), dim3(step_block<W>()), 0, s, q);
     else if (sizeof(W) == 4 && stored <= 24)
-      hipLaunchKernelGGL((step_many_kernel<W, C, 2, 0>), grid_for(q.one.B), dim3(kBlock), 0, s, q);
+      hipLaunchKernelGGL((step_many_kernel<W, C, 2, 0>), step_grid<W>(q.one.B), dim3(step_block<W>()), 0, s, q);
     else if (sizeof(W) == 8 && stored > 36 && stored <= 48)
-      hipLaunchKernelGGL((step_many_kernel<W, C, 4, 0>), grid_for(q.one.B), dim3(kBlock), 0, s, q);
+      hipLaunchKernelGGL((step_many_kernel<W, C, 4, 0>), step_grid<W>(q.one.B), dim3(step_block<W>()), 0, s, q);
     else
-      hipLaunchKernelGGL((step_many_kernel<W, C, 0, 0>), grid_for(q.one.B), dim3(kBlock), 0, s, q);
+      hipLaunchKernelGGL((step_many_kernel<W, C, 0, 0>), step_grid<W>(q.one.B), dim3(step_block<W>()), 0, s, q);
   }
 };
 template <typename W, int C>
@@ -713,7 +728,8 @@ int tetris_hip_supported_columns(int32_t* out, int cap) {
 
 int64_t tetris_hip_status_words(int64_t B) {
   if (B <= 0) return 0;
-  return 4 * (((B + kBlock - 1) / kBlock) * (kBlock / 64));
+  // one 16-byte slot per wavefront, rounded up to the largest tile a stepping kernel may use
+  return 4 * (((B + 1023) / 1024) * 16);
 }
 
 int tetris_hip_n_placements(int32_t catalogue_id, int32_t num_columns) {

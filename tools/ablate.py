@@ -27,15 +27,28 @@ for spec in os.environ.get("ABL_VARIANTS", "").split(";"):
 rows = int(os.environ.get("ABL_ROWS", "20"))
 pieces = os.environ.get("ABL_PIECES", "default")
 src = os.path.join(ROOT, "tetris_amd", "csrc", "tetris_kernels.hip")
-libs = {}
+# variants are built into build_variants/ (git-ignored, travels with gpurun) so they can be
+# compiled here, in parallel, instead of on GPU-box minutes: ABL_COMPILE_ONLY=1 stops after the build
+import glob  # noqa: E402
+newest_src = max(os.path.getmtime(f) for f in glob.glob(os.path.join(os.path.dirname(src), "*.h*")) +
+                 glob.glob(os.path.join(os.path.dirname(src), "*.inc")))
+vdir = os.path.join(ROOT, "build_variants")
+os.makedirs(vdir, exist_ok=True)
+procs = []
 for m in masks:
-    out = "/tmp/libtetris_abl_%d.so" % m
-    subprocess.check_call([build._hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC",
-                           "-DTET_ABLATE=%d" % (0 if m in per_mask_flags else m % 1000),
-                           "-DTET_STEP_WAVES=%d" % (0 if m in per_mask_flags else m // 1000)] + extra +
-                          per_mask_flags.get(m, []) +
-                          [src, "-o", out])
-    libs[m] = _lib._Binding(ctypes.CDLL(out))
+    out = os.path.join(vdir, "libtetris_abl_%d.so" % m)
+    if os.path.exists(out) and os.environ.get("ABL_REBUILD") != "1" and os.path.getmtime(out) > newest_src:
+        continue
+    procs.append(subprocess.Popen(
+        [build._hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC"] +
+        (["-DTET_ABLATE=%d" % (m % 1000), "-DTET_STEP_WAVES=%d" % (m // 1000)] if m not in per_mask_flags else []) +
+        extra + per_mask_flags.get(m, []) + [src, "-o", out]))
+for pr in procs:
+    if pr.wait() != 0:
+        sys.exit("variant build failed")
+if os.environ.get("ABL_COMPILE_ONLY") == "1":
+    sys.exit(0)
+libs = {m: _lib._Binding(ctypes.CDLL(os.path.join(vdir, "libtetris_abl_%d.so" % m))) for m in masks}
 
 B = 1 << 20
 base = VecTetris(10, rows, B, device="cuda", pieces=pieces, auto_reset=True, seed=0)

@@ -14,11 +14,9 @@ from tetris_amd import _lib, build, VecTetris  # noqa: E402
 
 m = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 rows = int(os.environ.get("ABL_ROWS", "20"))
-out = "/tmp/libtetris_abl_%d.so" % m
+out = os.path.join(ROOT, "build_variants", "libtetris_abl_%d.so" % m)  # built by tools/ablate.py (ABL_COMPILE_ONLY=1)
 if not os.path.exists(out):
-    src = os.path.join(ROOT, "tetris_amd", "csrc", "tetris_kernels.hip")
-    subprocess.check_call([build._hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC",
-                           "-DTET_ABLATE=%d" % (m % 1000), "-DTET_STEP_WAVES=%d" % (m // 1000), src, "-o", out])
+    sys.exit("build the variant first: ABL_COMPILE_ONLY=1 python tools/ablate.py %d" % m)
 env = VecTetris(10, rows, 1 << 20, device="cuda", auto_reset=True, seed=0)
 for t in range(150):
     env.step()
