@@ -198,21 +198,29 @@ TET_HD int bag_draw(uint32_t& bag, int n_pieces, uint32_t r16) {
 // One entry per (piece of the set, orientation slot k = 2L + o).  Every valid_mask field has a
 // whole word to itself on purpose: the kernels are integer-VALU bound while the LDS pipe idles,
 // so fields are fetched ready to use (wide LDS reads) instead of being shifted out of packed words.
-struct OrientEntry {
-  uint32_t desc;        // packed Orient descriptor (above)
-  uint32_t sh1[4];      // shifts into the level word for the real thresholds
-  uint32_t sh2[4];      // ... for the thresholds relaxed by one row
-  uint32_t resc[2][3];  // rescue rows t = 1, 2 (board rows R-3+t): has, j0, j1
-  uint32_t vert4;       // vertical Straight
-  uint32_t relax_free;  // relaxed thresholds unconstrained
+struct alignas(16) OrientEntry {  // 48 bytes = three 16-byte LDS reads (field order matters for that)
+  uint32_t sh[4];      // per footprint column j: 10 * (need_j - 1) + j, a shift into the level word
+  uint32_t rj0[2];     // rescue rows t = 1, 2 (board rows R-3+t): first piece column of that row,
+  uint32_t rj1[2];     //   last piece column; rj0 = 31 when the piece has no such row
+  uint32_t vert4;      // all ones for the vertical Straight, else 0
+  uint32_t desc;       // packed Orient descriptor (above)
+  uint32_t pad_[2];
 };
+static_assert(sizeof(OrientEntry) == 48, "table staging and LDS reads assume 48-byte entries");
 
 struct SetTable {
   OrientEntry orient[kMaxPieces][4];
   uint64_t fullmask[kMaxPieces];   // all existing placements (every one valid)
 };
 
-TET_HD uint32_t tab_u8(uint32_t f) { return f; }
+// The four entries of piece `np`.  The byte offset is laundered through a register so that the
+// compiler addresses every field as ONE base register + immediate offsets (it otherwise folds the
+// field offset into a separate multiply-add per LDS read).
+TET_HD const OrientEntry* piece_entries(const SetTable& tab, int np) {
+  uint32_t off = (uint32_t)np * (uint32_t)sizeof(tab.orient[0]);
+  TET_PIN(off);
+  return reinterpret_cast<const OrientEntry*>(reinterpret_cast<const char*>(&tab.orient[0][0]) + off);
+}
 
 // feature tables (tools/gen_feature_lut.py), staged in LDS by the kernels as ONE block of byte
 // tables, one per field so nothing has to be shifted or masked out of a packed entry:
@@ -470,20 +478,24 @@ TET_HD void bcts_features(const W (&col)[C], const int (&h)[C], int R, const uin
 // All columns c of one orientation are evaluated at once on C-bit column sets:
 //  * slack s_c = R - h_c; footprint column j needs s_{c+j} >= need_j = H - b_j.
 //    B_l = {c : s_c < l} for l = 1..4 (built with byte-parallel compares of the packed
-//    heights); OR_j (B_{need_j} >> j) = columns where the placement pokes >= 1 row above
-//    R-1 (I1); the same with need_j - 1 gives "pokes >= 2 rows" (I2).
+//    heights) sit in 10-bit fields of one 64-bit level word Z = [0 | B_1 | B_2 | B_3 | B_4];
+//    Z >> (10 (need_j - 1) + j) has B_{need_j - 1} >> j in bits 0-9 and B_{need_j} >> j in bits
+//    10-19, so ONE shift per footprint column yields both "pokes >= 1 row above R-1" (I1, OR
+//    over j of bits 10-19) and "pokes >= 2 rows" (I2, bits 0-9; level 0 is the empty field).
+//    Bits of c + j >= 10 spill over from the next field: those placements do not exist and are
+//    removed by fullmask.
 //  * e = 1 (I1 & ~I2): the anchor is exactly a = R+1-H, so the piece's row rho sits
 //    in board row R-3+t, t = rho+4-H.  That row becomes full iff all its missing
 //    columns lie inside the piece's (contiguous) run [c+j0, c+j1] of that row, i.e.
-//    c in [hi_t - j1, lo_t - j0] with lo_t/hi_t the lowest/highest missing column.
+//    c in [hi_t - j1, lo_t - j0] with lo_t/hi_t the lowest/highest missing column:
+//    with X_t = {c >= hi_t} and Y_t = {c <= lo_t} that set is (X_t >> j1) & (Y_t >> j0).
 //    One full row rescues the placement (n_cleared >= 1 = e).  Only rows below R can
 //    be full (no stack cell sits at row >= R), so t <= 2.
 //  * e >= 2 can only be rescued when H = 4 (vertical Straight): rows R-2 and R-1 must
-//    both miss exactly column c.
+//    both miss exactly column c (X_t & Y_t is that single column, or empty).
 template <typename W, int C>
-TET_HD uint64_t valid_mask(const W (&col)[C], const int (&h)[C], const OrientEntry (&tab)[4], uint64_t fullmask,
-                           int R) {
-  static_assert(C <= 10, "missing-cell rows are packed 3 bits per column into 32 bits");
+TET_HD uint64_t valid_mask(const W (&col)[C], const int (&h)[C], const OrientEntry* tab, uint64_t fullmask, int R) {
+  static_assert(C <= 10, "missing-cell rows are packed 3 bits per column into 32 bits; 10-bit level fields");
   uint32_t P[3] = {0u, 0u, 0u};
   uint32_t Fall = 0;
 #pragma unroll
@@ -502,51 +514,35 @@ TET_HD uint64_t valid_mask(const W (&col)[C], const int (&h)[C], const OrientEnt
       g |= ((((P[q] + K) & 0x80808080u) * 0x00204081u) >> 28) << (4 * q);  // gather the four bit-7s
     lv[l - 1] = g;
   }
-  const uint64_t BB = (uint64_t)(lv[0] | (lv[1] << 16)) | ((uint64_t)(lv[2] | (lv[3] << 16)) << 32);
+  const uint64_t Z = ((uint64_t)lv[0] << 10) | ((uint64_t)lv[1] << 20) | ((uint64_t)lv[2] << 30) |
+                     ((uint64_t)lv[3] << 40);
   const uint32_t Mall = ~Fall;  // missing cells, 3 bits per column
-  int lo[3], hi[3];
-  uint32_t single[3];
+  uint32_t X[3], Y[3];
 #pragma unroll
   for (int t = 0; t < 3; ++t) {
     const uint32_t m = (Mall >> t) & (0x09249249u & ((1u << (3 * C)) - 1u));  // bit 3c: column c misses row R-3+t
-    // (a row of a reachable board is never full, so m != 0)
-    lo[t] = m ? (__builtin_ctz(m) * 11) >> 5 : 0;          // /3
-    hi[t] = m ? ((31 - __builtin_clz(m)) * 11) >> 5 : 31;
-    single[t] = (lo[t] == hi[t]) ? (1u << lo[t]) : 0u;
+    const int lo = (__builtin_ctz(m | 0x80000000u) * 11) >> 5;                // / 3
+    const int hi = ((31 - __builtin_clz(m | 1u)) * 11) >> 5;
+    X[t] = ~0u << hi;
+    Y[t] = m ? (2u << lo) - 1u : 0u;  // a full row (only on boards that were set from outside) rescues nothing
   }
+  const uint32_t s0 = X[0] & Y[0], s1 = X[1] & Y[1], s2 = X[2] & Y[2];
+  const uint32_t rv1 = s0 | s1 | s2, rv2 = s1 & s2;  // vertical Straight: any of its three lower rows / both of R-2, R-1
   const uint32_t cm = (1u << C) - 1u;
   uint64_t mask = 0;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const OrientEntry& e = tab[k];
-    uint32_t i1 = 0, i2 = 0;
+    uint32_t r = 0;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      i1 |= (uint32_t)(BB >> tab_u8(e.sh1[j]));
-      i2 |= (uint32_t)(BB >> tab_u8(e.sh2[j]));
-    }
-    if (tab_u8(e.relax_free)) i2 = 0;
+    for (int j = 0; j < 4; ++j) r |= (uint32_t)(Z >> e.sh[j]);
+    const uint32_t i1 = r >> 10, i2 = r;
     // rescue by one cleared row (e = 1)
-    uint32_t r1 = 0;
-#pragma unroll
-    for (int t = 1; t < 3; ++t) {
-      const int j0 = (int)tab_u8(e.resc[t - 1][1]), j1 = (int)tab_u8(e.resc[t - 1][2]);
-      int c0 = hi[t] - j1;
-      c0 = c0 > 0 ? c0 : 0;
-      int len = lo[t] - j0 + 1 - c0;
-      len = len > 0 ? len : 0;
-      len = len < 16 ? len : 16;
-      const uint32_t iv = ((1u << len) - 1u) << c0;
-      r1 |= tab_u8(e.resc[t - 1][0]) ? iv : 0u;
-    }
-    uint32_t r2 = 0;
-    if (tab_u8(e.vert4)) {  // vertical Straight: any of its three lower rows / both of R-2, R-1
-      r1 = single[0] | single[1] | single[2];
-      r2 = single[1] & single[2];
-    }
+    uint32_t r1 = ((X[1] >> e.rj1[0]) & (Y[1] >> e.rj0[0])) | ((X[2] >> e.rj1[1]) & (Y[2] >> e.rj0[1]));
+    r1 = (rv1 & e.vert4) | (r1 & ~e.vert4);
+    const uint32_t r2 = rv2 & e.vert4;
     const uint32_t v = (~i1 | (~(i2 & ~r2) & r1)) & cm;
     mask |= (uint64_t)v << (C * k);
-    if (TET_FENCE_MASK) TET_SCHED_FENCE();  // keep one orientation's table words live at a time
   }
   return mask & fullmask;
 }
@@ -871,7 +867,7 @@ TET_HD void env_step(W (&col)[C], uint64_t& meta, int action, bool use_policy, c
   const uint32_t rnd = hash_env(cfg.key_step, env);
   int np = draw >= 0 ? draw : bag_draw(bag, cfg.n_pieces, rnd >> 16);
   uint64_t nmask = (TET_ABLATE & 2) ? (tab.fullmask[np] ^ (uint64_t)h[0])
-                                    : valid_mask<W, C>(col, h, tab.orient[np], tab.fullmask[np], R);
+                                    : valid_mask<W, C>(col, h, piece_entries(tab, np), tab.fullmask[np], R);
   int nnv = popc(nmask);
   int done = nnv == 0;
   out.reward = k - 1 + (done ? -100 : 0);  // game.py:86,89-90 (rewards :34-35)

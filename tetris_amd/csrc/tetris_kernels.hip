@@ -54,6 +54,16 @@ __device__ const FeatureLut kFeatureLut = {{
 }};
 static_assert(sizeof(FeatureLut) == tet::kFeatureLutBytes, "layout assumed by col_wells");
 
+// Everything a stepping workgroup keeps in LDS, as ONE object so that the placement table sits at
+// LDS address 0: its reads then fit the 8-bit offsets of ds_read2 / the offset field of
+// ds_read_b128 and need no per-read address arithmetic.
+template <typename W, int C, int BLK>
+struct alignas(16) StepLds {
+  SetTable tab;
+  alignas(16) uint8_t lut[tet::kFeatureLutBytes];
+  W lane_cols[C][BLK];  // per-lane scratch for the runtime-indexed stamp (bank = lane)
+};
+
 __device__ __forceinline__ void stage_hole_lut(uint8_t* lds) {
   const uint4* src = reinterpret_cast<const uint4*>(&kFeatureLut);
   uint4* dst = reinterpret_cast<uint4*>(lds);
@@ -153,9 +163,10 @@ __device__ __forceinline__ void load_inputs(const StepParams& p, uint32_t i, Ste
 template <typename W, int C, int NCH>
 __global__ __launch_bounds__(step_block<W>(), step_waves<W>()) void step_kernel(const StepParams p) {
   constexpr int kBlock = step_block<W>();  // shadows the file-wide tile size inside this kernel
-  __shared__ SetTable tab;
-  __shared__ __attribute__((aligned(16))) uint8_t hole_lut[tet::kFeatureLutBytes];
-  __shared__ W lane_cols[C][kBlock];  // per-lane scratch for the runtime-indexed stamp (bank = lane)
+  __shared__ StepLds<W, C, kBlock> lds;
+  SetTable& tab = lds.tab;
+  uint8_t* const hole_lut = lds.lut;
+  W (&lane_cols)[C][kBlock] = lds.lane_cols;
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
   const bool live = i < p.B;
   // Issue every global load of this lane first (board, meta, action, counters, its share of the
@@ -247,9 +258,10 @@ template <typename W, int C, int NCH, int POLICY>
 __global__ __launch_bounds__(step_block<W>(), POLICY == 0 ? step_waves<W>() : 1) void step_many_kernel(const StepManyParams q) {
   constexpr int kBlock = step_block<W>();  // shadows the file-wide tile size inside this kernel
   const StepParams& p = q.one;
-  __shared__ SetTable tab;
-  __shared__ __attribute__((aligned(16))) uint8_t hole_lut[tet::kFeatureLutBytes];
-  __shared__ W lane_cols[C][kBlock];
+  __shared__ StepLds<W, C, kBlock> lds;
+  SetTable& tab = lds.tab;
+  uint8_t* const hole_lut = lds.lut;
+  W (&lane_cols)[C][kBlock] = lds.lane_cols;
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
   const bool live = i < p.B;
   StepInputs<W, C> in;
@@ -390,7 +402,7 @@ __global__ __launch_bounds__(kBlock) void refresh_kernel(const RefreshParams p) 
   tet::heights_of<W, C>(col, h);
   const uint64_t meta = p.meta[i];
   const int piece = tet::meta_piece(meta);
-  const uint64_t mask = tet::valid_mask<W, C>(col, h, tab.orient[piece], tab.fullmask[piece], p.R);
+  const uint64_t mask = tet::valid_mask<W, C>(col, h, tet::piece_entries(tab, piece), tab.fullmask[piece], p.R);
   p.meta[i] = tet::meta_pack(mask, piece, tet::meta_bag(meta));
   if (p.n_valid_out) p.n_valid_out[i] = (uint8_t)tet::popc(mask);
 }
@@ -555,9 +567,10 @@ struct RolloutParams {
 // n rollouts back to back with the board in registers; nothing but the mean returns is written.
 template <typename W, int C>
 __global__ __launch_bounds__(kBlock) void rollouts_kernel(const RolloutParams p) {
-  __shared__ SetTable tab;
-  __shared__ __attribute__((aligned(16))) uint8_t hole_lut[tet::kFeatureLutBytes];
-  __shared__ W lane_cols[C][kBlock];
+  __shared__ StepLds<W, C, kBlock> lds;
+  SetTable& tab = lds.tab;
+  uint8_t* const hole_lut = lds.lut;
+  W (&lane_cols)[C][kBlock] = lds.lane_cols;
   stage_hole_lut(hole_lut);
   stage_table(tab, p.tab);
   const int64_t id = (int64_t)blockIdx.x * kBlock + threadIdx.x;

@@ -62,28 +62,13 @@ inline void pack_mask_fields(const CatOrient& o, OrientEntry* e) {
   int H = 0;
   for (int j = 0; j < o.w; ++j)
     if (o.b[j] + o.n[j] > H) H = o.b[j] + o.n[j];
-  int first2 = -1;
-  uint8_t sh2[4];
-  for (int j = 0; j < o.w; ++j) {
-    const int need = H - o.b[j];
-    e->sh1[j] = (uint32_t)(16 * (need - 1) + j);
-    if (need - 1 >= 1) {
-      sh2[j] = (uint8_t)(16 * (need - 2) + j);
-      if (first2 < 0) first2 = j;
-    } else {
-      sh2[j] = 0xFFu;  // unconstrained once relaxed
-    }
-  }
-  for (int j = o.w; j < 4; ++j) {  // absent columns repeat column 0's term (OR is idempotent)
-    e->sh1[j] = e->sh1[0];
-    sh2[j] = 0xFFu;
-  }
-  for (int j = 0; j < 4; ++j) e->sh2[j] = sh2[j] == 0xFFu ? (first2 >= 0 ? sh2[first2] : 0) : sh2[j];
-  e->vert4 = (o.w == 1 && H == 4) ? 1 : 0;
-  e->relax_free = first2 < 0 ? 1 : 0;
+  for (int j = 0; j < o.w; ++j) e->sh[j] = (uint32_t)(10 * (H - o.b[j] - 1) + j);
+  for (int j = o.w; j < 4; ++j) e->sh[j] = e->sh[0];  // absent columns repeat column 0's term (OR is idempotent)
+  e->vert4 = (o.w == 1 && H == 4) ? ~0u : 0u;
   for (int t = 1; t < 3; ++t) {  // board row R-3+t holds piece row rho when the anchor is R+1-H
     const int rho = t - 4 + H;
-    e->resc[t - 1][0] = e->resc[t - 1][1] = e->resc[t - 1][2] = 0;
+    e->rj0[t - 1] = 31;  // no such row: the interval is empty
+    e->rj1[t - 1] = 0;
     if (rho < 0 || rho > H - 2) continue;
     int j0 = -1, j1 = -1;
     for (int j = 0; j < o.w; ++j)
@@ -91,9 +76,8 @@ inline void pack_mask_fields(const CatOrient& o, OrientEntry* e) {
         if (j0 < 0) j0 = j;
         j1 = j;
       }
-    e->resc[t - 1][0] = 1;
-    e->resc[t - 1][1] = (uint32_t)j0;
-    e->resc[t - 1][2] = (uint32_t)j1;
+    e->rj0[t - 1] = (uint32_t)j0;
+    e->rj1[t - 1] = (uint32_t)j1;
   }
 }
 
