@@ -155,9 +155,10 @@ __device__ __forceinline__ void load_inputs(const StepParams& p, uint32_t i, Ste
   if (p.status) in.status = ld_off(reinterpret_cast<const uint4*>(p.status), (i >> 6) * 16u);  // this wave's slot
 }
 
-// One tile of 256 envs per workgroup.  (A persistent grid-stride variant that prefetches the
-// next tile was measured and is slower: the kernel is bound by integer-VALU issue, not by
-// exposed memory latency, and the prefetch registers cost occupancy.)
+// One tile of envs per workgroup.  (Persistent variants -- a grid-stride loop that prefetches the
+// next tile, or 2 / 4 / 8 tiles per workgroup with the tables staged once -- were measured and
+// are 3-20 % slower: the loop costs registers (94 instead of 73 VGPRs) and hardware dispatch
+// balances the CUs better than a static assignment.)
 // NCH = number of 12-row chunks of the stored board, fixed at compile time for the common
 // geometries (2: up to 24 stored rows, e.g. 10x20; 4: up to 48, e.g. 10x40), 0 = decide from R.
 template <typename W, int C, int NCH>
@@ -190,7 +191,7 @@ __global__ __launch_bounds__(step_block<W>(), step_waves<W>()) void step_kernel(
       tw[q] = (int)threadIdx.x + q * kBlock < kTabWords ? tsrc[threadIdx.x + q * kBlock] : 0u;
 #pragma unroll
     for (int q = 0; q < kLutPerLane; ++q)
-      if (kLutVecs % kBlock == 0 || (int)threadIdx.x + q * kBlock < kLutVecs)
+      if (!(TET_ABLATE & 128) && (kLutVecs % kBlock == 0 || (int)threadIdx.x + q * kBlock < kLutVecs))
         reinterpret_cast<uint4*>(hole_lut)[threadIdx.x + q * kBlock] = lv[q];
 #pragma unroll
     for (int q = 0; q < kTabPerLane; ++q)

@@ -2,7 +2,7 @@
 """Timing-only ablation of the step kernel: builds libtetris_hip variants with
 -DTET_ABLATE=<mask> (parts of the step removed -> wrong results, same memory
 traffic) and times the step kernel of each with HIP events, interleaved A/B in
-one process.  bit0 features, bit1 next-piece mask, bit2 exact-mask path, bit3 clear."""
+one process.  bit0 features, bit1 next-piece mask, bit3 clear, bit4 hole tables, bit5 wells, bit6 afterstates stores, bit7 table staging."""
 import ctypes
 import os
 import subprocess

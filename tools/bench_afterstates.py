@@ -20,12 +20,8 @@ env = VecTetris(10, rows, B, device="cuda", pieces=pieces, auto_reset=True, seed
 for t in range(150):
     env.step()
 abl = int(os.environ.get("ABL_MASK", "0"))
-if abl:
-    out = "/tmp/libtetris_abl_%d.so" % abl
-    subprocess.check_call([build._hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC",
-                           "-DTET_ABLATE=%d" % abl, os.path.join(ROOT, "tetris_amd", "csrc", "tetris_kernels.hip"),
-                           "-o", out])
-    env._lib = _lib._Binding(ctypes.CDLL(out))
+if abl:  # variant built by tools/ablate.py (ABL_COMPILE_ONLY=1 python tools/ablate.py <mask>)
+    env._lib = _lib._Binding(ctypes.CDLL(os.path.join(ROOT, "build_variants", "libtetris_abl_%d.so" % abl)))
 res = {}
 for inc in (False, True):
     for _ in range(3):
