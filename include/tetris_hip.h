@@ -61,7 +61,7 @@ enum {
   TETRIS_E_PIECES = -5,      /* bad piece list */
   TETRIS_E_BATCH = -6,       /* B <= 0 (tetris_hip_step: or B > 2^26 - 1 envs per call) */
   TETRIS_E_STREAM = -7,      /* replay stream given without cursor / length */
-  TETRIS_E_STRIDE = -8       /* afterstate strides not multiples of 4 floats / too small */
+  TETRIS_E_STRIDE = -8       /* afterstate strides not multiples of 4 floats / too small / matrix beyond 2^32 float4 */
 };
 
 /* Constructor arguments of game.Tetris (game.py:21-23) that shape the kernels. */

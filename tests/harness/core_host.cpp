@@ -153,7 +153,8 @@ void after_impl(const TetrisDesc* desc, const void* cols_, const uint64_t* meta,
     }
     int nv = tet::popc(valid), na = tet::popc(full);
     bool consistent = true;
-    tet::afterstates_env<W, C>(col, meta[i], tab, kHoleLut, R, [&](int sk, int sc, float (&f)[8]) {
+    tet::afterstates_env<W, C, 0>(col, meta[i], tab, kHoleLut, R, [&](bool has, int sk, int sc, float (&f)[8]) {
+          if (!has) return;
       const int s = C * sk + sc;
       // cross-checks (test harness only): (1) the incremental features against the full
       // evaluation of the same placement, (2) the cached mask against the direct terminal test
@@ -281,7 +282,8 @@ int tetris_host_policy_greedy(const TetrisDesc* desc, const void* cols_, const u
         for (int k = 0; k < desc->a_max; ++k) fall[k] = 0.f;
       float best = 0.f;
       int best_row = -1;
-      tet::afterstates_env<W, C>(col, meta[i], tab, kHoleLut, desc->num_rows, [&](int sk, int sc, float (&f)[8]) {
+      tet::afterstates_env<W, C, 0>(col, meta[i], tab, kHoleLut, desc->num_rows, [&](bool has, int sk, int sc, float (&f)[8]) {
+          if (!has) return;
         const float v = tet::fitness_of(f, w);
         if (fall) fall[tet::row_of_slot<C>(full, sk, sc)] = v;
         if ((valid >> (C * sk + sc)) & 1) {
@@ -369,7 +371,8 @@ int tetris_host_step_many(const TetrisDesc* desc, void* cols_, uint64_t* meta, i
           const uint64_t valid = tet::meta_mask(m);
           float best = 0.f;
           int best_row = -1;
-          tet::afterstates_env<W, C>(col, m, tab, kHoleLut, cfg.R, [&](int sk, int sc, float (&f)[8]) {
+          tet::afterstates_env<W, C, 0>(col, m, tab, kHoleLut, cfg.R, [&](bool has, int sk, int sc, float (&f)[8]) {
+          if (!has) return;
             if ((valid >> (C * sk + sc)) & 1) {
               const float v = tet::fitness_of(f, w);
               const int row = tet::row_of_slot<C>(valid, sk, sc);

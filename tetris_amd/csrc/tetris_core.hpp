@@ -618,13 +618,16 @@ TET_HD int stamp_scratch(W (&col)[C], W* scratch, int sstride, int c, uint32_t d
 }
 
 // ---- all afterstates of one env (game.py:67-80) -----------------------------------------
-// emit(field k = 2L + o, column c, f[8]) is called for every existing placement of the current piece with the BCTS
-// features of its afterstate.  The per-column feature terms of the current board are computed
-// once; a placement that clears no line changes at most its footprint columns, so only those
-// (plus the wells of the left neighbour and the row transitions / wells of the right one) are
-// re-evaluated -- with the left column c static, all of that indexes registers statically.
-// Placements that do clear lines (rare) take the full path.
-template <typename W, int C, typename Emit>
+// emit(has, field k = 2L + o, column c, f[8]) is called for every placement of the current piece
+// with the BCTS features of its afterstate.  On the device the calls are WAVE-UNIFORM: every lane
+// of the wavefront reaches every call (so the caller may cooperate across lanes, e.g. to merge
+// stores) and `has` tells whether this lane's env really has the placement (f is garbage
+// otherwise).  The per-column feature terms of the current board are computed once; a placement
+// that clears no line changes at most its footprint columns, so only those (plus the wells of the
+// left neighbour and the row transitions / wells of the right one) are re-evaluated -- with the
+// left column c static, all of that indexes registers statically.  Placements that do clear lines
+// (rare) take the full path.
+template <typename W, int C, int NCH, typename Emit>
 TET_HD void afterstates_env(const W (&col)[C], uint64_t meta, const SetTable& tab, const uint8_t* hole_lut, int R,
                             Emit&& emit) {
   int h[C];
@@ -647,9 +650,9 @@ TET_HD void afterstates_env(const W (&col)[C], uint64_t meta, const SetTable& ta
       const W Rr = (i == C - 1) ? wall : col[i + 1];
       const int hL = (i == 0) ? R : h[i - 1];
       int nh, e1, e7;
-      col_own<W>(col[i], h[i], R, hole_lut, HO[i], nh, e1, e7);
+      col_own<W, NCH>(col[i], h[i], R, hole_lut, HO[i], nh, e1, e7);
       const int e5 = col_rowtrans<W>(col[i], L, h[i], hL, nh_left);
-      const int e4 = col_wells<W>(col[i], L, Rr, h[i], R, i == 0, i == C - 1, hole_lut);
+      const int e4 = col_wells<W, NCH>(col[i], L, Rr, h[i], R, i == 0, i == C - 1, hole_lut);
       nh_left = nh;
       TA[i] = (uint32_t)e1 | ((uint32_t)nh << 10) | ((uint32_t)e5 << 20);
       TB[i] = (uint32_t)e4 | ((uint32_t)e7 << 16);
@@ -659,15 +662,28 @@ TET_HD void afterstates_env(const W (&col)[C], uint64_t meta, const SetTable& ta
   }
   const int plast = popc(col[C - 1]);
   uint64_t slow = 0;  // placements that clear lines: evaluated in full below
+  // Slots are walked in the reference's enumeration order (loop L, column c, orientation o) so
+  // that consecutive calls of emit produce consecutive feature rows: the four 32-byte rows that
+  // share a 128-byte line are then stored within a few hundred instructions of each other and
+  // merge in L2.  (Walking orientation-major left every line half written for thousands of
+  // cycles; the partially written lines were evicted and HBM took them at half rate.)
 #pragma unroll 1
-  for (int k = 0; k < 4; ++k) {
-    const Orient o = unpack_orient(tab.orient[piece][k].desc);
-    if (!o.exists) continue;
-    const bool u1 = TET_WAVE_ANY(o.w > 1), u2 = TET_WAVE_ANY(o.w > 2), u3 = TET_WAVE_ANY(o.w > 3);
+  for (int L = 0; L < 2; ++L) {
+    const uint32_t d0 = tab.orient[piece][2 * L].desc, d1 = tab.orient[piece][2 * L + 1].desc;
+    if (!TET_WAVE_ANY((d0 | d1) >> 31)) continue;
+    // widest footprint of each orientation over the wave: narrower pieces skip the extra columns
+    const bool v01 = TET_WAVE_ANY((d0 & 7u) > 1), v02 = TET_WAVE_ANY((d0 & 7u) > 2), v03 = TET_WAVE_ANY((d0 & 7u) > 3);
+    const bool v11 = TET_WAVE_ANY((d1 & 7u) > 1), v12 = TET_WAVE_ANY((d1 & 7u) > 2), v13 = TET_WAVE_ANY((d1 & 7u) > 3);
 #pragma unroll
     for (int c = 0; c < C; ++c) {
+#pragma unroll 1
+     for (int oi = 0; oi < 2; ++oi) {
+      const int k = 2 * L + oi;
+      const Orient o = unpack_orient(oi ? d1 : d0);
+      const bool u1 = oi ? v11 : v01, u2 = oi ? v12 : v02, u3 = oi ? v13 : v03;
       const int s = C * k + c;
-      if (!((full >> s) & 1)) continue;
+      const bool ex = (full >> s) & 1;  // this lane's piece has this placement
+      if (!TET_WAVE_ANY(ex)) continue;
       int a = 0;
 #pragma unroll
       for (int j = 0; j < 4; ++j)
@@ -687,10 +703,9 @@ TET_HD void afterstates_env(const W (&col)[C], uint64_t meta, const SetTable& ta
       W F = (W)~(W)0;
 #pragma unroll
       for (int i = 0; i < C; ++i) F &= (i >= c && i < c + 4) ? nb[i - c] : col[i];
-      if (F != 0) {
-        slow |= 1ull << s;
-        continue;
-      }
+      const bool fast = ex && F == 0;
+      if (ex && F != 0) slow |= 1ull << s;
+      if (!TET_WAVE_ANY(fast)) continue;
       // clamp helpers keep every array index static and in range even in dead branches
       constexpr int kz = 0;
       const int cm1 = c >= 1 ? c - 1 : kz, cm2 = c >= 2 ? c - 2 : kz;
@@ -701,7 +716,7 @@ TET_HD void afterstates_env(const W (&col)[C], uint64_t meta, const SetTable& ta
         if (i < c || i > c + 3) hrows |= HO[i];
       if (c >= 1) {  // left neighbour: only its wells see the new column c
         const W L2 = (c >= 2) ? col[cm2] : wall;
-        dB += (uint32_t)col_wells<W>(col[cm1], L2, nb[0], h[cm1], R, c == 1, false, hole_lut) - (TB[cm1] & 0xFFFFu);
+        dB += (uint32_t)col_wells<W, NCH>(col[cm1], L2, nb[0], h[cm1], R, c == 1, false, hole_lut) - (TB[cm1] & 0xFFFFu);
       }
       int nhprev = (c >= 1) ? (int)((TA[cm1] >> 10) & 1023u) : 0;
 #pragma unroll
@@ -717,9 +732,9 @@ TET_HD void afterstates_env(const W (&col)[C], uint64_t meta, const SetTable& ta
           if (fullre) {
             W ho;
             int nh, e1, e7;
-            col_own<W>(nb[j], nhh[j], R, hole_lut, ho, nh, e1, e7);
+            col_own<W, NCH>(nb[j], nhh[j], R, hole_lut, ho, nh, e1, e7);
             const int e5 = col_rowtrans<W>(nb[j], L, nhh[j], hL, nhprev);
-            const int e4 = col_wells<W>(nb[j], L, Rr, nhh[j], R, c + j == 0, c + j == C - 1, hole_lut);
+            const int e4 = col_wells<W, NCH>(nb[j], L, Rr, nhh[j], R, c + j == 0, c + j == C - 1, hole_lut);
             dA += ((uint32_t)e1 | ((uint32_t)nh << 10) | ((uint32_t)e5 << 20)) - TA[i];
             dB += ((uint32_t)e4 | ((uint32_t)e7 << 16)) - TB[i];
             hrows |= ho;
@@ -728,7 +743,7 @@ TET_HD void afterstates_env(const W (&col)[C], uint64_t meta, const SetTable& ta
             hrows |= HO[i];
             if (part) {  // right neighbour of the widest footprint in this wave
               const int e5 = col_rowtrans<W>(col[i], L, h[i], hL, nhprev);
-              const int e4 = col_wells<W>(col[i], L, Rr, h[i], R, false, i == C - 1, hole_lut);
+              const int e4 = col_wells<W, NCH>(col[i], L, Rr, h[i], R, false, i == C - 1, hole_lut);
               dA += ((uint32_t)e5 << 20) - (TA[i] & 0xFFF00000u);
               dB += (uint32_t)e4 - (TB[i] & 0xFFFFu);
             }
@@ -740,7 +755,7 @@ TET_HD void afterstates_env(const W (&col)[C], uint64_t meta, const SetTable& ta
         const int i = c + 4 < C ? c + 4 : C - 1, ip = i + 1 < C ? i + 1 : C - 1;
         const W Rr = (c + 5 < C) ? col[ip] : wall;
         dA += ((uint32_t)col_rowtrans<W>(col[i], nb[3], h[i], nhh[3], nhprev) << 20) - (TA[i] & 0xFFF00000u);
-        dB += (uint32_t)col_wells<W>(col[i], nb[3], Rr, h[i], R, false, i == C - 1, hole_lut) - (TB[i] & 0xFFFFu);
+        dB += (uint32_t)col_wells<W, NCH>(col[i], nb[3], Rr, h[i], R, false, i == C - 1, hole_lut) - (TB[i] & 0xFFFFu);
       }
       const int lj = (C - 1 - c >= 0 && C - 1 - c < 4) ? C - 1 - c : 0;
       const int pl = (C - 1 >= c && C - 1 < c + 4) ? popc(nb[lj]) : plast;
@@ -753,11 +768,14 @@ TET_HD void afterstates_env(const W (&col)[C], uint64_t meta, const SetTable& ta
       f[5] = (float)(R - pl + (int)(dA >> 20));
       f[6] = 0.0f;
       f[7] = (float)(dB >> 16);
-      emit(k, c, f);
+      emit(fast, k, c, f);
+      TET_SCHED_FENCE();  // one placement at a time: interleaving the unrolled columns only costs registers
+     }
     }
   }
-  while (slow != 0) {  // line-clearing placements (rare): full evaluation, state.py:33 onwards
-    const int s = bitlen(slow) - 1;
+  while (TET_WAVE_ANY(slow != 0) && !(TET_ABLATE & 256)) {  // line-clearing placements (rare): full evaluation, state.py:33 onwards
+    const bool has = slow != 0;  // lanes that are done keep pace on placement 0 (it always exists)
+    const int s = has ? bitlen(slow) - 1 : 0;
     slow &= ~(1ull << s);
     W fb[C];
 #pragma unroll
@@ -771,8 +789,8 @@ TET_HD void afterstates_env(const W (&col)[C], uint64_t meta, const SetTable& ta
     const int kk = clear_lines<W, C>(fb, pbits, &eroded);
     heights_of<W, C>(fb, fh);
     float f[8];
-    bcts_features<W, C>(fb, fh, R, hole_lut, aa, (int)((od >> 3) & 7u), eroded, kk, f);
-    emit(sk, sc, f);
+    bcts_features<W, C, NCH>(fb, fh, R, hole_lut, aa, (int)((od >> 3) & 7u), eroded, kk, f);
+    emit(has, sk, sc, f);
   }
 }
 
@@ -923,7 +941,8 @@ TET_HD int rollout_env(const W (&col0)[C], uint64_t meta0, int a0, int length, i
         const uint64_t valid = meta_mask(meta);
         float best = 0.f;
         int best_row = -1;
-        afterstates_env<W, C>(col, meta, tab, hole_lut, R, [&](int sk, int sc, float (&f)[8]) {
+        afterstates_env<W, C, 0>(col, meta, tab, hole_lut, R, [&](bool has, int sk, int sc, float (&f)[8]) {
+          if (!has) return;
           if ((valid >> (C * sk + sc)) & 1) {
             const float v = fitness_of(f, w);
             const int row = row_of_slot<C>(valid, sk, sc);

@@ -283,7 +283,8 @@ __global__ __launch_bounds__(step_block<W>(), POLICY == 0 ? step_waves<W>() : 1)
         const uint64_t valid = tet::meta_mask(in.meta);
         float best = 0.f;
         int best_row = -1;
-        tet::afterstates_env<W, C>(in.col, in.meta, tab, hole_lut, cfg.R, [&](int sk, int sc, float (&f)[8]) {
+        tet::afterstates_env<W, C, 0>(in.col, in.meta, tab, hole_lut, cfg.R, [&](bool has, int sk, int sc, float (&f)[8]) {
+          if (!has) return;
           if ((valid >> (C * sk + sc)) & 1) {
             const float v = tet::fitness_of(f, q.w);
             const int row = tet::row_of_slot<C>(valid, sk, sc);
@@ -430,14 +431,44 @@ struct AfterParams {
 #ifndef TET_AFTER_WAVES
 #define TET_AFTER_WAVES 1
 #endif
-template <typename W, int C>
+
+// Feature rows are 32 bytes and the rows of different envs are far apart, so a plain store of one
+// row per lane is 64 separate 16-byte write requests per instruction -- the kernel was bound by
+// the L2 write-request rate (75 M requests per launch), not by bytes.  Lanes therefore pair up
+// through LDS: in two steps the even/odd lane of a pair write the two 16-byte halves of ONE row
+// (first the even lane's row, then the odd lane's), so every request carries a whole 32-byte row.
+// All lanes of the wave must call this together (afterstates_env's emit is wave-uniform).
+struct alignas(16) RowExchange {
+  float4 half[kBlock][2];   // [lane][low / high half of the row]
+  uint32_t at[kBlock];      // destination of the row in float4 units, ~0u = nothing to store
+};
+__device__ __forceinline__ void store_row_paired(RowExchange& x, float* base, bool has, uint32_t at4,
+                                                 const float (&f)[8]) {
+  const unsigned t = threadIdx.x;
+  x.half[t][0] = make_float4(f[0], f[1], f[2], f[3]);
+  x.half[t][1] = make_float4(f[4], f[5], f[6], f[7]);
+  x.at[t] = has ? at4 : ~0u;
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (unsigned w = 0; w < 2; ++w) {
+    const unsigned src = (t & ~1u) | w, part = t & 1u;
+    const uint32_t d = x.at[src];
+    const float4 v = x.half[src][part];
+    if (d != ~0u) reinterpret_cast<float4*>(base)[(size_t)d + part] = v;
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
+template <typename W, int C, int NCH>
 __global__ __launch_bounds__(kBlock, TET_AFTER_WAVES) void afterstates_kernel(const AfterParams p) {
   __shared__ SetTable tab;
   __shared__ __attribute__((aligned(16))) uint8_t hole_lut[tet::kFeatureLutBytes];
+  __shared__ RowExchange xch;
   stage_hole_lut(hole_lut);
   stage_table(tab, p.tab);
-  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (i >= p.B) return;
+  const int64_t i0 = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const bool live = i0 < p.B;
+  const int64_t i = live ? i0 : p.B - 1;  // lanes past the end keep pace on the last env and store nothing
   const W* cols = static_cast<const W*>(p.cols);
   W col[C];
 #pragma unroll
@@ -447,16 +478,17 @@ __global__ __launch_bounds__(kBlock, TET_AFTER_WAVES) void afterstates_kernel(co
   const uint64_t full = tab.fullmask[piece];
   const uint64_t valid = tet::meta_mask(meta) & full;  // non-terminal slots (kept fresh by step/reset/refresh)
   // env-major ([B][a_max][8]: row_stride 8) keeps a wave's 36 rows x 64 envs inside one 72 KiB
-  // span; action-major ([a_max][B][8]: env_stride 8) coalesces each row but walks 36 regions
-  // 32 MiB apart and measured 1.4x slower (TLB reach), so env-major is the default upstream
-  float* out_valid = p.feats + i * p.env_stride;
-  float* out_all = p.feats_all ? p.feats_all + i * p.env_stride : nullptr;
-  const int64_t rs = p.row_stride;
+  // span; action-major ([a_max][B][8]: env_stride 8) walks 36 regions 32 MiB apart and measured
+  // 1.4x slower (TLB reach), so env-major is the default upstream.  Offsets are in float4 units
+  // (the C-ABI checks that the whole matrix stays below 2^32 of them).
+  const uint32_t es4 = (uint32_t)(p.env_stride / 4), rs4 = (uint32_t)(p.row_stride / 4);
+  const uint32_t env4 = (uint32_t)i * es4;
   const int nv = tet::popc(valid), na = tet::popc(full);
   float sink = 0.f;
-  tet::afterstates_env<W, C>(col, meta, tab, hole_lut, p.R, [&](int sk, int sc, float (&f)[8]) {
+  tet::afterstates_env<W, C, NCH>(col, meta, tab, hole_lut, p.R, [&](bool has, int sk, int sc, float (&f)[8]) {
+    has = has && live;
     if (TET_ABLATE & 64) {  // timing experiment: no feature stores
-      sink += f[0] + f[1] + f[2] + f[3] + f[4] + f[5] + f[6] + f[7] + (float)(sk + sc);
+      if (has) sink += f[0] + f[1] + f[2] + f[3] + f[4] + f[5] + f[6] + f[7] + (float)(sk + sc);
       return;
     }
     if (p.has_direct_by) {
@@ -464,35 +496,25 @@ __global__ __launch_bounds__(kBlock, TET_AFTER_WAVES) void afterstates_kernel(co
       for (int q = 0; q < 8; ++q) f[q] *= p.direct_by[q];
     }
     // the row of a placement follows the reference's enumeration order (tet::row_of_slot)
-    if (out_all) {
-      float4* d = reinterpret_cast<float4*>(out_all + tet::row_of_slot<C>(full, sk, sc) * rs);
-      d[0] = make_float4(f[0], f[1], f[2], f[3]);
-      d[1] = make_float4(f[4], f[5], f[6], f[7]);
-    }
-    if ((valid >> (C * sk + sc)) & 1) {  // game.py:69
-      float4* d = reinterpret_cast<float4*>(out_valid + tet::row_of_slot<C>(valid, sk, sc) * rs);
-      d[0] = make_float4(f[0], f[1], f[2], f[3]);
-      d[1] = make_float4(f[4], f[5], f[6], f[7]);
-    }
+    if (p.feats_all)
+      store_row_paired(xch, p.feats_all, has, env4 + (uint32_t)tet::row_of_slot<C>(full, sk, sc) * rs4, f);
+    store_row_paired(xch, p.feats, has && ((valid >> (C * sk + sc)) & 1),  // game.py:69
+                     env4 + (uint32_t)tet::row_of_slot<C>(valid, sk, sc) * rs4, f);
   });
   if (TET_ABLATE & 64) {
-    out_valid[0] = sink;
+    if (live) p.feats[i * p.env_stride] = sink;
     return;
   }
-  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int k = nv; k < p.a_max; ++k) {
-    float4* d = reinterpret_cast<float4*>(out_valid + k * rs);
-    d[0] = z;
-    d[1] = z;
+  const float zero[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int k = 0; k < p.a_max; ++k) {  // zero the rows past the last placement (wave-uniform loop)
+    const bool pad = live && k >= nv, pad_all = live && k >= na;
+    if (__ballot(pad) != 0ull) store_row_paired(xch, p.feats, pad, env4 + (uint32_t)k * rs4, zero);
+    if (p.feats_all && __ballot(pad_all) != 0ull) store_row_paired(xch, p.feats_all, pad_all, env4 + (uint32_t)k * rs4, zero);
   }
-  if (out_all)
-    for (int k = na; k < p.a_max; ++k) {
-      float4* d = reinterpret_cast<float4*>(out_all + k * rs);
-      d[0] = z;
-      d[1] = z;
-    }
-  p.n_valid[i] = (uint8_t)nv;
-  if (p.n_all) p.n_all[i] = (uint8_t)na;
+  if (live) {
+    p.n_valid[i] = (uint8_t)nv;
+    if (p.n_all) p.n_all[i] = (uint8_t)na;
+  }
 }
 
 struct GreedyParams {
@@ -511,7 +533,7 @@ struct GreedyParams {
 // Tetris.get_best_policy / fitness (game.py:102-120) for every env: the fitness of every
 // placement (raw order, terminal included, like game.py:103) and the best NON-terminal action.
 // The [B][a_max][8] feature matrix never touches HBM.
-template <typename W, int C>
+template <typename W, int C, int NCH>
 __global__ __launch_bounds__(kBlock) void greedy_kernel(const GreedyParams p) {
   __shared__ SetTable tab;
   __shared__ __attribute__((aligned(16))) uint8_t hole_lut[tet::kFeatureLutBytes];
@@ -530,7 +552,8 @@ __global__ __launch_bounds__(kBlock) void greedy_kernel(const GreedyParams p) {
   float* fall = p.fitness_all ? p.fitness_all + i * (int64_t)p.a_max : nullptr;
   float best = 0.f;
   int best_row = -1;
-  tet::afterstates_env<W, C>(col, meta, tab, hole_lut, p.R, [&](int sk, int sc, float (&f)[8]) {
+  tet::afterstates_env<W, C, NCH>(col, meta, tab, hole_lut, p.R, [&](bool has, int sk, int sc, float (&f)[8]) {
+          if (!has) return;
     const float v = tet::fitness_of(f, p.w);
     if (fall) fall[tet::row_of_slot<C>(full, sk, sc)] = v;
     if ((valid >> (C * sk + sc)) & 1) {
@@ -700,13 +723,25 @@ struct LaunchRollouts {
 template <typename W, int C>
 struct LaunchGreedy {
   static void run(const GreedyParams& p, hipStream_t s) {
-    hipLaunchKernelGGL((greedy_kernel<W, C>), grid_for(p.B), dim3(kBlock), 0, s, p);
+    const int stored = p.R + 4;  // compile-time chunk counts as in LaunchStep
+    if (sizeof(W) == 4 && stored <= 24)
+      hipLaunchKernelGGL((greedy_kernel<W, C, 2>), grid_for(p.B), dim3(kBlock), 0, s, p);
+    else if (sizeof(W) == 8 && stored > 36 && stored <= 48)
+      hipLaunchKernelGGL((greedy_kernel<W, C, 4>), grid_for(p.B), dim3(kBlock), 0, s, p);
+    else
+      hipLaunchKernelGGL((greedy_kernel<W, C, 0>), grid_for(p.B), dim3(kBlock), 0, s, p);
   }
 };
 template <typename W, int C>
 struct LaunchAfter {
   static void run(const AfterParams& p, hipStream_t s) {
-    hipLaunchKernelGGL((afterstates_kernel<W, C>), grid_for(p.B), dim3(kBlock), 0, s, p);
+    const int stored = p.R + 4;
+    if (sizeof(W) == 4 && stored <= 24)
+      hipLaunchKernelGGL((afterstates_kernel<W, C, 2>), grid_for(p.B), dim3(kBlock), 0, s, p);
+    else if (sizeof(W) == 8 && stored > 36 && stored <= 48)
+      hipLaunchKernelGGL((afterstates_kernel<W, C, 4>), grid_for(p.B), dim3(kBlock), 0, s, p);
+    else
+      hipLaunchKernelGGL((afterstates_kernel<W, C, 0>), grid_for(p.B), dim3(kBlock), 0, s, p);
   }
 };
 
@@ -876,6 +911,8 @@ int tetris_hip_afterstates(const TetrisDesc* desc, const void* cols, const uint6
   p.n_all = n_all;
   p.B = B;
   if (env_stride % 4 || row_stride % 4 || env_stride < 8 || row_stride < 8) return TETRIS_E_STRIDE;
+  // the kernel addresses rows with 32-bit float4 indices
+  if ((B - 1) * (env_stride / 4) + (int64_t)(desc->a_max - 1) * (row_stride / 4) + 2 >= 0xFFFFFFFFll) return TETRIS_E_STRIDE;
   p.env_stride = env_stride;
   p.row_stride = row_stride;
   p.R = desc->num_rows;
