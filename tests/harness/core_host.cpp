@@ -24,6 +24,14 @@ const FeatureLut kFeatureLutHost = {{
 #include "../../tetris_amd/csrc/tetris_feature_lut.inc"
 }};
 const uint8_t* const kHoleLut = reinterpret_cast<const uint8_t*>(&kFeatureLutHost);
+// the 10-row-chunk set the stepping kernels use on u32 boards of up to 20 rows (LaunchStep)
+struct alignas(16) FeatureLut10 {
+  uint8_t bytes[tet::kFeatureLut10Bytes];
+};
+const FeatureLut10 kFeatureLut10Host = {{
+#include "../../tetris_amd/csrc/tetris_feature_lut10.inc"
+}};
+const uint8_t* const kHoleLut10 = reinterpret_cast<const uint8_t*>(&kFeatureLut10Host);
 
 template <typename W, int C>
 void step_impl(const TetrisDesc* desc, void* cols_, uint64_t* meta, const int32_t* action, int32_t* action_out,
@@ -57,9 +65,12 @@ void step_impl(const TetrisDesc* desc, void* cols_, uint64_t* meta, const int32_
     }
     tet::StepOut out;
     W scratch[C];
-    tet::env_step<W, C>(col, m, action ? action[i] : -1, action == nullptr, tab, kHoleLut, scratch, 1, cfg,
-                        (uint32_t)(env_offset + i),
-                        draw, draw_reset, out);
+    if (sizeof(W) == 4 && cfg.R <= 20)  // same dispatch as the library's LaunchStep
+      tet::env_step<W, C, 2, 10>(col, m, action ? action[i] : -1, action == nullptr, tab, kHoleLut10, scratch, 1,
+                                 cfg, (uint32_t)(env_offset + i), draw, draw_reset, out);
+    else
+      tet::env_step<W, C>(col, m, action ? action[i] : -1, action == nullptr, tab, kHoleLut, scratch, 1, cfg,
+                          (uint32_t)(env_offset + i), draw, draw_reset, out);
     if (action_out) action_out[i] = out.action;
     if (!out.invalid) {
       for (int c = 0; c < C; ++c) cols[(int64_t)c * B + i] = col[c];

@@ -224,12 +224,19 @@ TET_HD const OrientEntry* piece_entries(const SetTable& tab, int np) {
 
 // feature tables (tools/gen_feature_lut.py), staged in LDS by the kernels as ONE block of byte
 // tables, one per field so nothing has to be shifted or masked out of a packed entry:
-// hole_A, hole_u (13-bit index), wells_S, wells_lead, wells_trail (12-bit index)
-constexpr int kHoleLutSize = 1 << 13;
-constexpr int kWellsLutEntries = 1 << 12;
-constexpr int kLutHoleA = 0, kLutHoleU = kHoleLutSize, kLutWellsS = 2 * kHoleLutSize;
-constexpr int kLutWellsLead = kLutWellsS + kWellsLutEntries, kLutWellsTrail = kLutWellsLead + kWellsLutEntries;
-constexpr int kFeatureLutBytes = kLutWellsTrail + kWellsLutEntries;
+// hole_A, hole_u (index: a CR-row chunk of a column + the cell above), wells_S, wells_lead,
+// wells_trail (index: a CR-row chunk of a column's well cells).  CR = 12 rows per chunk in general
+// (28 KiB); the stepping kernels use CR = 10 (7 KiB) on boards of up to 20 rows, where two
+// chunks cover every cell a non-terminal board can hold.
+template <int CR>
+struct LutLayout {
+  static constexpr int kHoleEntries = 1 << (CR + 1), kWellsEntries = 1 << CR;
+  static constexpr int kHoleA = 0, kHoleU = kHoleEntries, kWellsS = 2 * kHoleEntries;
+  static constexpr int kWellsLead = kWellsS + kWellsEntries, kWellsTrail = kWellsLead + kWellsEntries;
+  static constexpr int kBytes = kWellsTrail + kWellsEntries;
+};
+constexpr int kFeatureLutBytes = LutLayout<12>::kBytes;
+constexpr int kFeatureLut10Bytes = LutLayout<10>::kBytes;
 
 // bit c -> bit 2c (c < 16)
 TET_HD uint32_t spread2(uint32_t x) {
@@ -338,25 +345,25 @@ TET_HD int clear_lines(W (&col)[C], const W (&pbits)[4], int* eroded_cells) {
 // so they are 2 * (number of run tops) -- the same u.
 // NCH > 0: the board has exactly NCH 12-row chunks (compile-time); NCH = 0: decide from R.
 // Columns hold no bits at or above row R + 4, so the top chunk of an NCH board needs no mask.
-template <typename W, int NCH = 0>
+template <typename W, int NCH = 0, int CR = 12>
 TET_HD void col_own(W x, int hi, int R, const uint8_t* lut, W& ho, int& nh, int& f1, int& f7) {
   ho = (W)(~x & lowmask<W>(hi));                   // holes (state.py:210-213)
   nh = popc(ho);
-  const uint8_t* lut_a = lut + kLutHoleA;
-  const uint8_t* lut_u = lut + kLutHoleU;
+  const uint8_t* lut_a = lut + LutLayout<CR>::kHoleA;
+  const uint8_t* lut_u = lut + LutLayout<CR>::kHoleU;
   int d7 = 0, u = 0;
   if (!(TET_ABLATE & 16)) {
 #pragma unroll
-    for (int k = 0; 12 * k < (int)(8 * sizeof(W)) - 1; ++k) {
+    for (int k = 0; CR * k < (int)(8 * sizeof(W)) - 1; ++k) {
       // rows beyond the stored ones are zero: entry 0 adds nothing, so extra chunks are harmless
-      if (NCH > 0 ? k < NCH : (k < 2 || 12 * k < R + 4)) {
-        const uint32_t up = (uint32_t)(x >> (12 * k));
-        const uint32_t idx = (NCH > 0 && k == NCH - 1) ? up : (up & 0x1FFFu);
+      if (NCH > 0 ? k < NCH : (k < 2 || CR * k < R + 4)) {
+        const uint32_t up = (uint32_t)(x >> (CR * k));
+        const uint32_t idx = (NCH > 0 && k == NCH - 1) ? up : (up & (uint32_t)(LutLayout<CR>::kHoleEntries - 1));
         const int uk = lut_u[idx];
         u += uk;
         d7 += lut_a[idx];
-        const bool more = NCH > 0 ? k + 1 < NCH : (12 * (k + 1) < R + 4);  // rows above this chunk exist
-        if (12 * (k + 1) < (int)(8 * sizeof(W)) && more) d7 += uk * popc((W)(x >> (12 * (k + 1))));
+        const bool more = NCH > 0 ? k + 1 < NCH : (CR * (k + 1) < R + 4);  // rows above this chunk exist
+        if (CR * (k + 1) < (int)(8 * sizeof(W)) && more) d7 += uk * popc((W)(x >> (CR * (k + 1))));
       }
     }
   }
@@ -381,19 +388,19 @@ TET_HD int col_rowtrans(W x, W L, int hi, int hL, int nh_left) {
 // columns the wall side is cut at max(h, R).  Every maximal vertical run of k well cells adds
 // k(k+1)/2: summed per 12-row chunk through the wells tables (S, lead, trail) with a carry for
 // runs that cross chunk borders -- no data-dependent loop.  (A full chunk has trail = lead = 12.)
-template <typename W, int NCH = 0>
+template <typename W, int NCH = 0, int CR = 12>
 TET_HD int col_wells(W x, W L, W Rr, int hi, int R, bool left_wall, bool right_wall, const uint8_t* lut) {
   W w = (W)(~x & L & Rr);
   if (left_wall || right_wall) w = (W)(w & lowmask<W>(hi > R ? hi : R));
-  const uint8_t* lut_s = lut + kLutWellsS;
-  const uint8_t* lut_lead = lut + kLutWellsLead;
-  const uint8_t* lut_trail = lut + kLutWellsTrail;
+  const uint8_t* lut_s = lut + LutLayout<CR>::kWellsS;
+  const uint8_t* lut_lead = lut + LutLayout<CR>::kWellsLead;
+  const uint8_t* lut_trail = lut + LutLayout<CR>::kWellsTrail;
   int total = 0, carry = 0;
 #pragma unroll
-  for (int k = 0; 12 * k < (int)(8 * sizeof(W)) - 1; ++k) {
-    if (NCH > 0 ? k < NCH : (k < 2 || 12 * k < R + 4)) {  // rows beyond the stored ones hold no well cells
-      const uint32_t up = (uint32_t)(w >> (12 * k));
-      const uint32_t idx = (NCH > 0 && k == NCH - 1) ? up : (up & 0xFFFu);
+  for (int k = 0; CR * k < (int)(8 * sizeof(W)) - 1; ++k) {
+    if (NCH > 0 ? k < NCH : (k < 2 || CR * k < R + 4)) {  // rows beyond the stored ones hold no well cells
+      const uint32_t up = (uint32_t)(w >> (CR * k));
+      const uint32_t idx = (NCH > 0 && k == NCH - 1) ? up : (up & (uint32_t)(LutLayout<CR>::kWellsEntries - 1));
       const bool last = NCH > 0 && k == NCH - 1;
       total += lut_s[idx];
       if (k == 0) {
@@ -403,7 +410,7 @@ TET_HD int col_wells(W x, W L, W Rr, int hi, int R, bool left_wall, bool right_w
         total += carry * lead;
         if (!last) {
           const int trail = lut_trail[idx];  // read unconditionally: a select, not a branch around the load
-          carry = (lead == 12) ? carry + 12 : trail;
+          carry = (lead == CR) ? carry + CR : trail;
         }
       }
     }
@@ -412,7 +419,7 @@ TET_HD int col_wells(W x, W L, W Rr, int hi, int R, bool left_wall, bool right_w
 }
 
 // state.py:175-280.  out = f0,f1,f2,f4,f5,f7.
-template <typename W, int C, int NCH = 0>
+template <typename W, int C, int NCH = 0, int CR = 12>
 TET_HD void board_features(const W (&col)[C], const int (&h)[C], int R, const uint8_t* hole_lut,
                            int& rows_with_holes, int& col_trans, int& holes, int& wells, int& row_trans,
                            int& hole_depth) {
@@ -429,14 +436,14 @@ TET_HD void board_features(const W (&col)[C], const int (&h)[C], int R, const ui
     const int hL = (i == 0) ? R : h[i - 1];       // state.py:179 wall height = num_rows
     W ho;
     int nh, d1, d7;
-    col_own<W, NCH>(col[i], h[i], R, hole_lut, ho, nh, d1, d7);
+    col_own<W, NCH, CR>(col[i], h[i], R, hole_lut, ho, nh, d1, d7);
     f1 += d1;
     f2 += nh;
     f7 += d7;
     hole_rows |= ho;                              // state.py:215
     f5 += col_rowtrans<W>(col[i], L, h[i], hL, nh_left);
     nh_left = nh;
-    f4 += col_wells<W, NCH>(col[i], L, Rr, h[i], R, i == 0, i == C - 1, hole_lut);
+    f4 += col_wells<W, NCH, CR>(col[i], L, Rr, h[i], R, i == 0, i == C - 1, hole_lut);
     if (TET_FENCE_EVERY > 0 && i % TET_FENCE_EVERY == TET_FENCE_EVERY - 1 && i + 1 < C) {
       TET_PIN(f1);
       TET_PIN(f2);
@@ -455,11 +462,11 @@ TET_HD void board_features(const W (&col)[C], const int (&h)[C], int R, const ui
 }
 
 // state.py:97-107: the eight BCTS features as float32
-template <typename W, int C, int NCH = 0>
+template <typename W, int C, int NCH = 0, int CR = 12>
 TET_HD void bcts_features(const W (&col)[C], const int (&h)[C], int R, const uint8_t* hole_lut, int anchor_row,
                           int H, int eroded_cells, int n_cleared, float (&f)[8]) {
   int f0, f1, f2, f4, f5, f7;
-  board_features<W, C, NCH>(col, h, R, hole_lut, f0, f1, f2, f4, f5, f7);
+  board_features<W, C, NCH, CR>(col, h, R, hole_lut, f0, f1, f2, f4, f5, f7);
   f[0] = (float)f0;
   f[1] = (float)f1;
   f[2] = (float)f2;
@@ -837,7 +844,7 @@ TET_HD int policy_random(uint32_t key_policy, uint32_t env, int n_valid) {
 
 // `action` < 0 with use_policy: draw it with policy_random.  `draw` = replay piece for the
 // step draw (or -1: use the bag), `draw_reset` = replay piece for the reset draw (or -1).
-template <typename W, int C, int NCH = 0>
+template <typename W, int C, int NCH = 0, int CR = 12>
 TET_HD void env_step(W (&col)[C], uint64_t& meta, int action, bool use_policy, const SetTable& tab,
                      const uint8_t* hole_lut, W* scratch, int sstride, const StepCfg& cfg, uint32_t env, int draw,
                      int draw_reset, StepOut& out) {
@@ -875,7 +882,7 @@ TET_HD void env_step(W (&col)[C], uint64_t& meta, int action, bool use_policy, c
 #pragma unroll
     for (int i = 0; i < 8; ++i) out.obs[i] = (float)h[i];
   } else
-  bcts_features<W, C, NCH>(col, h, R, hole_lut, a, oH, eroded, k, out.obs);  // game.py:91
+  bcts_features<W, C, NCH, CR>(col, h, R, hole_lut, a, oH, eroded, k, out.obs);  // game.py:91
   if (cfg.has_direct_by) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) out.obs[i] *= cfg.direct_by[i];

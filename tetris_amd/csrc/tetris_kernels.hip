@@ -39,6 +39,9 @@ constexpr int step_waves() { return TET_STEP_WAVES ? TET_STEP_WAVES : (sizeof(W)
 #ifndef TET_STEP_BLOCK
 #define TET_STEP_BLOCK 0
 #endif
+#ifndef TET_LUT10
+#define TET_LUT10 1   // 0: always the 12-row-chunk tables (A/B timing)
+#endif
 template <typename W>
 constexpr int step_block() { return TET_STEP_BLOCK ? TET_STEP_BLOCK : (sizeof(W) == 4 ? 512 : 256); }
 
@@ -53,21 +56,33 @@ __device__ const FeatureLut kFeatureLut = {{
 #include "tetris_feature_lut.inc"
 }};
 static_assert(sizeof(FeatureLut) == tet::kFeatureLutBytes, "layout assumed by col_wells");
+// the same tables for 10-row chunks (7 KiB): stepping kernels on boards of up to 20 rows
+struct alignas(16) FeatureLut10 {
+  uint8_t bytes[tet::kFeatureLut10Bytes];
+};
+__device__ const FeatureLut10 kFeatureLut10 = {{
+#include "tetris_feature_lut10.inc"
+}};
+template <int CR>
+__device__ __forceinline__ const uint4* feature_lut_src() {
+  return CR == 10 ? reinterpret_cast<const uint4*>(&kFeatureLut10) : reinterpret_cast<const uint4*>(&kFeatureLut);
+}
 
 // Everything a stepping workgroup keeps in LDS, as ONE object so that the placement table sits at
 // LDS address 0: its reads then fit the 8-bit offsets of ds_read2 / the offset field of
 // ds_read_b128 and need no per-read address arithmetic.
-template <typename W, int C, int BLK>
+template <typename W, int C, int BLK, int CR>
 struct alignas(16) StepLds {
   SetTable tab;
-  alignas(16) uint8_t lut[tet::kFeatureLutBytes];
+  alignas(16) uint8_t lut[tet::LutLayout<CR>::kBytes];
   W lane_cols[C][BLK];  // per-lane scratch for the runtime-indexed stamp (bank = lane)
 };
 
+template <int CR = 12>
 __device__ __forceinline__ void stage_hole_lut(uint8_t* lds) {
-  const uint4* src = reinterpret_cast<const uint4*>(&kFeatureLut);
+  const uint4* src = feature_lut_src<CR>();
   uint4* dst = reinterpret_cast<uint4*>(lds);
-  for (int t = threadIdx.x; t < tet::kFeatureLutBytes / 16; t += blockDim.x) dst[t] = src[t];
+  for (int t = threadIdx.x; t < tet::LutLayout<CR>::kBytes / 16; t += blockDim.x) dst[t] = src[t];
 }
 
 __device__ __forceinline__ void stage_table(SetTable& lds, const SetTable& arg) {
@@ -161,10 +176,10 @@ __device__ __forceinline__ void load_inputs(const StepParams& p, uint32_t i, Ste
 // balances the CUs better than a static assignment.)
 // NCH = number of 12-row chunks of the stored board, fixed at compile time for the common
 // geometries (2: up to 24 stored rows, e.g. 10x20; 4: up to 48, e.g. 10x40), 0 = decide from R.
-template <typename W, int C, int NCH>
+template <typename W, int C, int NCH, int CR>
 __global__ __launch_bounds__(step_block<W>(), step_waves<W>()) void step_kernel(const StepParams p) {
   constexpr int kBlock = step_block<W>();  // shadows the file-wide tile size inside this kernel
-  __shared__ StepLds<W, C, kBlock> lds;
+  __shared__ StepLds<W, C, kBlock, CR> lds;
   SetTable& tab = lds.tab;
   uint8_t* const hole_lut = lds.lut;
   W (&lane_cols)[C][kBlock] = lds.lane_cols;
@@ -175,8 +190,8 @@ __global__ __launch_bounds__(step_block<W>(), step_waves<W>()) void step_kernel(
   StepInputs<W, C> in;
   load_inputs<W, C>(p, i, in);
   {
-    constexpr int kLutVecs = tet::kFeatureLutBytes / 16, kLutPerLane = (kLutVecs + kBlock - 1) / kBlock;
-    const uint4* lsrc = reinterpret_cast<const uint4*>(&kFeatureLut);
+    constexpr int kLutVecs = tet::LutLayout<CR>::kBytes / 16, kLutPerLane = (kLutVecs + kBlock - 1) / kBlock;
+    const uint4* lsrc = feature_lut_src<CR>();
     uint4 lv[kLutPerLane];
 #pragma unroll
     for (int q = 0; q < kLutPerLane; ++q) {  // (clamped, not predicated: keeps lv[] in registers)
@@ -202,7 +217,7 @@ __global__ __launch_bounds__(step_block<W>(), step_waves<W>()) void step_kernel(
   int invalid = 0, done = 0, lines = 0;
   if (live) {
     tet::StepOut out;
-    tet::env_step<W, C, NCH>(in.col, in.meta, in.action, p.action == nullptr, tab, hole_lut,
+    tet::env_step<W, C, NCH, CR>(in.col, in.meta, in.action, p.action == nullptr, tab, hole_lut,
                              &lane_cols[0][threadIdx.x], kBlock, p.cfg, p.env_offset + i, in.draw, in.draw_reset,
                              out);
     invalid = out.invalid;
@@ -255,11 +270,12 @@ struct StepManyParams {
 // (uniform random / greedy linear): the board and meta stay in registers between steps, every
 // step's outputs are written to trajectory buffers [K][B]...; bit-identical to K launches of
 // step_kernel with step_idx0, step_idx0 + 1, ...  (the per-step keys are re-derived on device).
-template <typename W, int C, int NCH, int POLICY>
+template <typename W, int C, int NCH, int POLICY, int CR>
 __global__ __launch_bounds__(step_block<W>(), POLICY == 0 ? step_waves<W>() : 1) void step_many_kernel(const StepManyParams q) {
+  static_assert(POLICY == 0 || CR == 12, "the greedy policy evaluates terminal afterstates too: 12-row chunks");
   constexpr int kBlock = step_block<W>();  // shadows the file-wide tile size inside this kernel
   const StepParams& p = q.one;
-  __shared__ StepLds<W, C, kBlock> lds;
+  __shared__ StepLds<W, C, kBlock, CR> lds;
   SetTable& tab = lds.tab;
   uint8_t* const hole_lut = lds.lut;
   W (&lane_cols)[C][kBlock] = lds.lane_cols;
@@ -267,7 +283,7 @@ __global__ __launch_bounds__(step_block<W>(), POLICY == 0 ? step_waves<W>() : 1)
   const bool live = i < p.B;
   StepInputs<W, C> in;
   load_inputs<W, C>(p, i, in);
-  stage_hole_lut(hole_lut);
+  stage_hole_lut<CR>(hole_lut);
   stage_table(tab, p.tab);
   unsigned n_inv = 0, n_done = 0, n_lines = 0, n_steps = 0;
   StepCfg cfg = p.cfg;
@@ -298,7 +314,7 @@ __global__ __launch_bounds__(step_block<W>(), POLICY == 0 ? step_waves<W>() : 1)
         use_policy = false;
       }
       tet::StepOut out;
-      tet::env_step<W, C, NCH>(in.col, in.meta, action, use_policy, tab, hole_lut, &lane_cols[0][threadIdx.x], kBlock,
+      tet::env_step<W, C, NCH, CR>(in.col, in.meta, action, use_policy, tab, hole_lut, &lane_cols[0][threadIdx.x], kBlock,
                                cfg, p.env_offset + i, -1, -1, out);
       invalid = out.invalid;
       const uint32_t e = (uint32_t)k * p.B + i;  // element index in the [K][B] trajectory buffers
@@ -591,7 +607,7 @@ struct RolloutParams {
 // n rollouts back to back with the board in registers; nothing but the mean returns is written.
 template <typename W, int C>
 __global__ __launch_bounds__(kBlock) void rollouts_kernel(const RolloutParams p) {
-  __shared__ StepLds<W, C, kBlock> lds;
+  __shared__ StepLds<W, C, kBlock, 12> lds;
   SetTable& tab = lds.tab;
   uint8_t* const hole_lut = lds.lut;
   W (&lane_cols)[C][kBlock] = lds.lane_cols;
@@ -679,13 +695,18 @@ int dispatch(const TetrisDesc* d, const P& p, hipStream_t s) {
 template <typename W, int C>
 struct LaunchStep {
   static void run(const StepParams& p, hipStream_t s) {
+    // a step only evaluates the features of a NON-terminal board (cells below row R): up to R = 20
+    // two 10-row chunks cover it and the tables are the 7 KiB set; otherwise 12-row chunks,
+    // counted at compile time for the common geometries
     const int stored = p.cfg.R + 4;
-    if (sizeof(W) == 4 && stored <= 24)
-      hipLaunchKernelGGL((step_kernel<W, C, 2>), step_grid<W>(p.B), dim3(step_block<W>()), 0, s, p);
+    if (sizeof(W) == 4 && p.cfg.R <= 20 && TET_LUT10)
+      hipLaunchKernelGGL((step_kernel<W, C, 2, 10>), step_grid<W>(p.B), dim3(step_block<W>()), 0, s, p);
+    else if (sizeof(W) == 4 && stored <= 24)
+      hipLaunchKernelGGL((step_kernel<W, C, 2, 12>), step_grid<W>(p.B), dim3(step_block<W>()), 0, s, p);
     else if (sizeof(W) == 8 && stored > 36 && stored <= 48)
-      hipLaunchKernelGGL((step_kernel<W, C, 4>), step_grid<W>(p.B), dim3(step_block<W>()), 0, s, p);
+      hipLaunchKernelGGL((step_kernel<W, C, 4, 12>), step_grid<W>(p.B), dim3(step_block<W>()), 0, s, p);
     else
-      hipLaunchKernelGGL((step_kernel<W, C, 0>), step_grid<W>(p.B), dim3(step_block<W>()), 0, s, p);
+      hipLaunchKernelGGL((step_kernel<W, C, 0, 12>), step_grid<W>(p.B), dim3(step_block<W>()), 0, s, p);
   }
 };
 template <typename W, int C>
@@ -693,13 +714,15 @@ struct LaunchStepMany {
   static void run(const StepManyParams& q, hipStream_t s) {
     const int stored = q.one.cfg.R + 4;
     if (q.policy == 1)
-      hipLaunchKernelGGL((step_many_kernel<W, C, 0, 1>), step_grid<W>(q.one.B), dim3(step_block<W>()), 0, s, q);
+      hipLaunchKernelGGL((step_many_kernel<W, C, 0, 1, 12>), step_grid<W>(q.one.B), dim3(step_block<W>()), 0, s, q);
+    else if (sizeof(W) == 4 && q.one.cfg.R <= 20 && TET_LUT10)
+      hipLaunchKernelGGL((step_many_kernel<W, C, 2, 0, 10>), step_grid<W>(q.one.B), dim3(step_block<W>()), 0, s, q);
     else if (sizeof(W) == 4 && stored <= 24)
-      hipLaunchKernelGGL((step_many_kernel<W, C, 2, 0>), step_grid<W>(q.one.B), dim3(step_block<W>()), 0, s, q);
+      hipLaunchKernelGGL((step_many_kernel<W, C, 2, 0, 12>), step_grid<W>(q.one.B), dim3(step_block<W>()), 0, s, q);
     else if (sizeof(W) == 8 && stored > 36 && stored <= 48)
-      hipLaunchKernelGGL((step_many_kernel<W, C, 4, 0>), step_grid<W>(q.one.B), dim3(step_block<W>()), 0, s, q);
+      hipLaunchKernelGGL((step_many_kernel<W, C, 4, 0, 12>), step_grid<W>(q.one.B), dim3(step_block<W>()), 0, s, q);
     else
-      hipLaunchKernelGGL((step_many_kernel<W, C, 0, 0>), step_grid<W>(q.one.B), dim3(step_block<W>()), 0, s, q);
+      hipLaunchKernelGGL((step_many_kernel<W, C, 0, 0, 12>), step_grid<W>(q.one.B), dim3(step_block<W>()), 0, s, q);
   }
 };
 template <typename W, int C>
