@@ -254,7 +254,13 @@ def edge_geometries(device, orc):
     eps = 0
     for C, R, pieces, B in [(10, 4, "default", 130), (10, 27, "standard7", 65), (10, 28, "standard7", 63),
                             (10, 59, "default", 31), (6, 4, "standard7", 1), (8, 27, "default", 257),
-                            (6, 59, "standard7", 64)]:
+                            (6, 59, "standard7", 64),
+                            # either side of every kernel-variant switch: 10-row / 12-row table chunks (R = 20 | 21),
+                            # chunk borders inside the board (R = 10, 12, 13), compile-time chunk counts of the
+                            # u64 kernels (stored rows 36 | 37 and 48 | 49)
+                            (6, 20, "default", 77), (10, 21, "standard7", 70), (10, 10, "standard7", 45),
+                            (8, 12, "default", 33), (10, 13, "standard7", 40), (10, 32, "default", 50),
+                            (10, 33, "standard7", 50), (10, 44, "default", 40), (10, 45, "standard7", 40)]:
         eps += lockstep(device, orc, C, R, B, pieces, steps=90, seed=3, check_after_every=15)
     assert eps > 0
 

@@ -916,7 +916,7 @@ TET_HD void env_step(W (&col)[C], uint64_t& meta, int action, bool use_policy, c
 // sum of the rewards of steps 2..length (game.py:133-146; the first reward is not counted).
 // policy 0: uniform random valid action; 1: greedy on the linear fitness `w` (first maximum).
 // Pieces come from a fork of the env's bag driven by hash(key0 + t, uid); the env is untouched.
-template <typename W, int C>
+template <typename W, int C, int NCH = 0>
 TET_HD int rollout_env(const W (&col0)[C], uint64_t meta0, int a0, int length, int policy, const float (&w)[8],
                        const SetTable& tab, const uint8_t* hole_lut, W* scratch, int sstride, int R, int n_pieces,
                        uint32_t key0, uint32_t uid) {
@@ -948,7 +948,7 @@ TET_HD int rollout_env(const W (&col0)[C], uint64_t meta0, int a0, int length, i
         const uint64_t valid = meta_mask(meta);
         float best = 0.f;
         int best_row = -1;
-        afterstates_env<W, C, 0>(col, meta, tab, hole_lut, R, [&](bool has, int sk, int sc, float (&f)[8]) {
+        afterstates_env<W, C, NCH>(col, meta, tab, hole_lut, R, [&](bool has, int sk, int sc, float (&f)[8]) {
           if (!has) return;
           if ((valid >> (C * sk + sc)) & 1) {
             const float v = fitness_of(f, w);
@@ -963,7 +963,7 @@ TET_HD int rollout_env(const W (&col0)[C], uint64_t meta0, int a0, int length, i
       }
     }
     StepOut out;
-    env_step<W, C>(col, meta, action, use_policy, tab, hole_lut, scratch, sstride, cfg, uid, -1, -1, out);
+    env_step<W, C, NCH>(col, meta, action, use_policy, tab, hole_lut, scratch, sstride, cfg, uid, -1, -1, out);
     if (out.done || out.invalid) return -1;  // game.py:135-138,143-145
     if (t > 0) ret += out.reward;
   }

@@ -299,7 +299,7 @@ __global__ __launch_bounds__(step_block<W>(), POLICY == 0 ? step_waves<W>() : 1)
         const uint64_t valid = tet::meta_mask(in.meta);
         float best = 0.f;
         int best_row = -1;
-        tet::afterstates_env<W, C, 0>(in.col, in.meta, tab, hole_lut, cfg.R, [&](bool has, int sk, int sc, float (&f)[8]) {
+        tet::afterstates_env<W, C, NCH>(in.col, in.meta, tab, hole_lut, cfg.R, [&](bool has, int sk, int sc, float (&f)[8]) {
           if (!has) return;
           if ((valid >> (C * sk + sc)) & 1) {
             const float v = tet::fitness_of(f, q.w);
@@ -605,7 +605,7 @@ struct RolloutParams {
 
 // Tetris.perform_rollouts (game.py:150-160) as a fan-out: one lane per (env, first action) runs its
 // n rollouts back to back with the board in registers; nothing but the mean returns is written.
-template <typename W, int C>
+template <typename W, int C, int NCH>
 __global__ __launch_bounds__(kBlock) void rollouts_kernel(const RolloutParams p) {
   __shared__ StepLds<W, C, kBlock, 12> lds;
   SetTable& tab = lds.tab;
@@ -629,7 +629,7 @@ __global__ __launch_bounds__(kBlock) void rollouts_kernel(const RolloutParams p)
     for (int r = 0; r < p.n; ++r) {
       const uint64_t uid = ((uint64_t)(p.env_offset + i) * (uint64_t)p.a_max + (uint64_t)a0) * (uint64_t)p.n + r;
       const uint32_t key0 = tet::mix32(p.key ^ ((uint32_t)(uid >> 32) * 0x9E3779B1u));
-      sum += tet::rollout_env<W, C>(col, meta, a0, p.length, p.policy, p.w, tab, hole_lut,
+      sum += tet::rollout_env<W, C, NCH>(col, meta, a0, p.length, p.policy, p.w, tab, hole_lut,
                                     &lane_cols[0][threadIdx.x], kBlock, p.R, p.n_pieces, key0, (uint32_t)uid);
     }
     mean = (double)sum / (double)p.n;
@@ -713,7 +713,11 @@ template <typename W, int C>
 struct LaunchStepMany {
   static void run(const StepManyParams& q, hipStream_t s) {
     const int stored = q.one.cfg.R + 4;
-    if (q.policy == 1)
+    if (q.policy == 1 && sizeof(W) == 4 && stored <= 24)
+      hipLaunchKernelGGL((step_many_kernel<W, C, 2, 1, 12>), step_grid<W>(q.one.B), dim3(step_block<W>()), 0, s, q);
+    else if (q.policy == 1 && sizeof(W) == 8 && stored > 36 && stored <= 48)
+      hipLaunchKernelGGL((step_many_kernel<W, C, 4, 1, 12>), step_grid<W>(q.one.B), dim3(step_block<W>()), 0, s, q);
+    else if (q.policy == 1)
       hipLaunchKernelGGL((step_many_kernel<W, C, 0, 1, 12>), step_grid<W>(q.one.B), dim3(step_block<W>()), 0, s, q);
     else if (sizeof(W) == 4 && q.one.cfg.R <= 20 && TET_LUT10)
       hipLaunchKernelGGL((step_many_kernel<W, C, 2, 0, 10>), step_grid<W>(q.one.B), dim3(step_block<W>()), 0, s, q);
@@ -740,7 +744,13 @@ struct LaunchRefresh {
 template <typename W, int C>
 struct LaunchRollouts {
   static void run(const RolloutParams& p, hipStream_t s) {
-    hipLaunchKernelGGL((rollouts_kernel<W, C>), grid_for(p.B * p.a_max), dim3(kBlock), 0, s, p);
+    const int stored = p.R + 4;
+    if (sizeof(W) == 4 && stored <= 24)
+      hipLaunchKernelGGL((rollouts_kernel<W, C, 2>), grid_for(p.B * p.a_max), dim3(kBlock), 0, s, p);
+    else if (sizeof(W) == 8 && stored > 36 && stored <= 48)
+      hipLaunchKernelGGL((rollouts_kernel<W, C, 4>), grid_for(p.B * p.a_max), dim3(kBlock), 0, s, p);
+    else
+      hipLaunchKernelGGL((rollouts_kernel<W, C, 0>), grid_for(p.B * p.a_max), dim3(kBlock), 0, s, p);
   }
 };
 template <typename W, int C>

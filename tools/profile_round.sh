@@ -39,4 +39,10 @@ timeout -k 10 200 python3 tools/bench_afterstates.py > $OUT/afterstates_10x20.js
 timeout -k 10 250 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_after -- python3 tools/bench_afterstates.py > $OUT/trace_after.log 2>&1 || exit 1
 cp $(ls $OUT/trace_after/*/*kernel_stats.csv | head -1) $OUT/afterstates_kernel_stats.csv
 echo "afterstates done"
+
+# 6. policy-side kernels (greedy, fused greedy step, rollouts) and the store-path microbenchmarks
+timeout -k 10 300 python3 tools/bench_policy.py > $OUT/policy_kernels_10x20.json 2>/dev/null || exit 1
+timeout -k 10 100 python3 tools/ubench/fill_bw.py > $OUT/ubench_fill_bw.txt 2>/dev/null || exit 1
+if [ -x build_variants/row_store ]; then timeout -k 10 60 ./build_variants/row_store > $OUT/ubench_row_store.txt 2>/dev/null || exit 1; fi
+echo "policy + ubench done"
 ls -la $OUT
