@@ -68,6 +68,9 @@ void step_impl(const TetrisDesc* desc, void* cols_, uint64_t* meta, const int32_
     if (sizeof(W) == 4 && cfg.R <= 20)  // same dispatch as the library's LaunchStep
       tet::env_step<W, C, 2, 10>(col, m, action ? action[i] : -1, action == nullptr, tab, kHoleLut10, scratch, 1,
                                  cfg, (uint32_t)(env_offset + i), draw, draw_reset, out);
+    else if (sizeof(W) == 8 && cfg.R <= 40)
+      tet::env_step<W, C, 4, 10>(col, m, action ? action[i] : -1, action == nullptr, tab, kHoleLut10, scratch, 1,
+                                 cfg, (uint32_t)(env_offset + i), draw, draw_reset, out);
     else
       tet::env_step<W, C>(col, m, action ? action[i] : -1, action == nullptr, tab, kHoleLut, scratch, 1, cfg,
                           (uint32_t)(env_offset + i), draw, draw_reset, out);

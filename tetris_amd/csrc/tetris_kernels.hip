@@ -28,8 +28,8 @@ constexpr int kBlock = 256;
 #ifndef TET_STEP_WAVES
 #define TET_STEP_WAVES 0
 #endif
-template <typename W>
-constexpr int step_waves() { return TET_STEP_WAVES ? TET_STEP_WAVES : (sizeof(W) == 4 ? 5 : 3); }
+template <typename W, int CR = 12>
+constexpr int step_waves() { return TET_STEP_WAVES ? TET_STEP_WAVES : (sizeof(W) == 4 ? 5 : (CR == 10 ? 4 : 3)); }
 
 // envs per workgroup of the step kernel: the feature tables are staged once per workgroup, so a
 // larger tile amortises that L2 -> LDS traffic over more envs.  u32 boards: 512 (8 waves = 2 per
@@ -177,7 +177,7 @@ __device__ __forceinline__ void load_inputs(const StepParams& p, uint32_t i, Ste
 // NCH = number of 12-row chunks of the stored board, fixed at compile time for the common
 // geometries (2: up to 24 stored rows, e.g. 10x20; 4: up to 48, e.g. 10x40), 0 = decide from R.
 template <typename W, int C, int NCH, int CR>
-__global__ __launch_bounds__(step_block<W>(), step_waves<W>()) void step_kernel(const StepParams p) {
+__global__ __launch_bounds__(step_block<W>(), (step_waves<W, CR>())) void step_kernel(const StepParams p) {
   constexpr int kBlock = step_block<W>();  // shadows the file-wide tile size inside this kernel
   __shared__ StepLds<W, C, kBlock, CR> lds;
   SetTable& tab = lds.tab;
@@ -271,7 +271,7 @@ struct StepManyParams {
 // step's outputs are written to trajectory buffers [K][B]...; bit-identical to K launches of
 // step_kernel with step_idx0, step_idx0 + 1, ...  (the per-step keys are re-derived on device).
 template <typename W, int C, int NCH, int POLICY, int CR>
-__global__ __launch_bounds__(step_block<W>(), POLICY == 0 ? step_waves<W>() : 1) void step_many_kernel(const StepManyParams q) {
+__global__ __launch_bounds__(step_block<W>(), (POLICY == 0 ? step_waves<W, CR>() : 1)) void step_many_kernel(const StepManyParams q) {
   static_assert(POLICY == 0 || CR == 12, "the greedy policy evaluates terminal afterstates too: 12-row chunks");
   constexpr int kBlock = step_block<W>();  // shadows the file-wide tile size inside this kernel
   const StepParams& p = q.one;
@@ -696,11 +696,13 @@ template <typename W, int C>
 struct LaunchStep {
   static void run(const StepParams& p, hipStream_t s) {
     // a step only evaluates the features of a NON-terminal board (cells below row R): up to R = 20
-    // two 10-row chunks cover it and the tables are the 7 KiB set; otherwise 12-row chunks,
-    // counted at compile time for the common geometries
+    // (u32) two 10-row chunks cover it, up to R = 40 (u64) four, and the tables are the 7 KiB
+    // set; otherwise 12-row chunks, counted at compile time for the common geometries
     const int stored = p.cfg.R + 4;
     if (sizeof(W) == 4 && p.cfg.R <= 20 && TET_LUT10)
       hipLaunchKernelGGL((step_kernel<W, C, 2, 10>), step_grid<W>(p.B), dim3(step_block<W>()), 0, s, p);
+    else if (sizeof(W) == 8 && p.cfg.R <= 40 && TET_LUT10)  // four 10-row chunks: 10x40 (BASELINE config 5)
+      hipLaunchKernelGGL((step_kernel<W, C, 4, 10>), step_grid<W>(p.B), dim3(step_block<W>()), 0, s, p);
     else if (sizeof(W) == 4 && stored <= 24)
       hipLaunchKernelGGL((step_kernel<W, C, 2, 12>), step_grid<W>(p.B), dim3(step_block<W>()), 0, s, p);
     else if (sizeof(W) == 8 && stored > 36 && stored <= 48)
@@ -721,6 +723,8 @@ struct LaunchStepMany {
       hipLaunchKernelGGL((step_many_kernel<W, C, 0, 1, 12>), step_grid<W>(q.one.B), dim3(step_block<W>()), 0, s, q);
     else if (sizeof(W) == 4 && q.one.cfg.R <= 20 && TET_LUT10)
       hipLaunchKernelGGL((step_many_kernel<W, C, 2, 0, 10>), step_grid<W>(q.one.B), dim3(step_block<W>()), 0, s, q);
+    else if (sizeof(W) == 8 && q.one.cfg.R <= 40 && TET_LUT10)
+      hipLaunchKernelGGL((step_many_kernel<W, C, 4, 0, 10>), step_grid<W>(q.one.B), dim3(step_block<W>()), 0, s, q);
     else if (sizeof(W) == 4 && stored <= 24)
       hipLaunchKernelGGL((step_many_kernel<W, C, 2, 0, 12>), step_grid<W>(q.one.B), dim3(step_block<W>()), 0, s, q);
     else if (sizeof(W) == 8 && stored > 36 && stored <= 48)
