@@ -212,7 +212,10 @@ int tetris_hip_policy_random(const uint8_t* n_valid, int32_t* action, uint64_t s
 int tetris_hip_decode(const TetrisDesc* desc, const void* cols, int8_t* cells, int32_t* heights,
                       int64_t B, void* hip_stream);
 
-/* reference layout -> bitboards (inverse of tetris_hip_decode) */
+/* reference layout -> bitboards (inverse of tetris_hip_decode).  Boards handed to the stepping
+ * entry points must be states the game can reach: a board with a cell at row >= R is a terminal
+ * state (state.py:33-36) -- tetris_hip_refresh gives it no valid placement, so it is never
+ * stepped and its features are never evaluated by tetris_hip_step. */
 int tetris_hip_encode(const TetrisDesc* desc, const int8_t* cells, void* cols, int64_t B,
                       void* hip_stream);
 
