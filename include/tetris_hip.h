@@ -212,10 +212,11 @@ int tetris_hip_policy_random(const uint8_t* n_valid, int32_t* action, uint64_t s
 int tetris_hip_decode(const TetrisDesc* desc, const void* cols, int8_t* cells, int32_t* heights,
                       int64_t B, void* hip_stream);
 
-/* reference layout -> bitboards (inverse of tetris_hip_decode).  Boards handed to the stepping
- * entry points must be states the game can reach: a board with a cell at row >= R is a terminal
- * state (state.py:33-36) -- tetris_hip_refresh gives it no valid placement, so it is never
- * stepped and its features are never evaluated by tetris_hip_step. */
+/* reference layout -> bitboards (inverse of tetris_hip_decode).  Boards handed to
+ * tetris_hip_refresh / tetris_hip_step / tetris_hip_afterstates must be states a game can be in:
+ * no cell at row >= R.  (A board with such a cell is a terminal State, state.py:33-36, which the
+ * reference never steps from, game.py:69; the placement mask and the stepping kernels' feature
+ * tables assume there is none.  The Python host refuses such boards in set_boards.) */
 int tetris_hip_encode(const TetrisDesc* desc, const int8_t* cells, void* cols, int64_t B,
                       void* hip_stream);
 

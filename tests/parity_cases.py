@@ -387,3 +387,24 @@ def step_many_equals_steps(device, orc, B=700):
         obs, rew, done, lines = b.step(ba.clone())
         assert torch.equal(out["action"][k], ba) and torch.equal(out["obs"][k], obs) and torch.equal(out["done"][k], done)
     assert torch.equal(a.cols, b.cols) and torch.equal(a.meta, b.meta)
+
+
+def terminal_boards_are_refused(device):
+    """A board with a cell in the overflow rows is a terminal State (state.py:33-36): set_boards refuses
+    it (the kernels assume current boards have none) and the facade's is_game_over answers True."""
+    import pytest
+    from tetris_amd import Tetris, VecTetris
+    from tetris_amd.state import State
+    C, R = 10, 20
+    env = VecTetris(C, R, 2, device=device, auto_reset=False, seed=0)
+    cells = np.zeros((2, R + 4, C), np.int8)
+    cells[0, :R, 3] = 1            # column 3 filled to the top legal row: still a legal board
+    env.set_boards(torch.from_numpy(cells), piece=np.array([0, 0]))
+    assert int(env.n_valid[0]) > 0
+    cells[1, R, 5] = 1             # a cell in row R
+    with pytest.raises(ValueError):
+        env.set_boards(torch.from_numpy(cells), piece=np.array([0, 0]))
+    game = Tetris(C, R, device=device)
+    rep = np.zeros((R + 4, C), np.int_)
+    rep[:R + 1, 2] = 1
+    assert game.is_game_over(State(rep)) is True

@@ -109,3 +109,7 @@ def test_rollouts(orc):
 
 def test_step_many_equals_steps(orc):
     pc.step_many_equals_steps(DEV, orc)
+
+
+def test_terminal_boards_are_refused():
+    pc.terminal_boards_are_refused(DEV)

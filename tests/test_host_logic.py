@@ -59,3 +59,7 @@ def test_rollouts(host_backend, orc):
 
 def test_step_many_equals_steps(host_backend, orc):
     pc.step_many_equals_steps(DEV, orc)
+
+
+def test_terminal_boards_are_refused(host_backend):
+    pc.terminal_boards_are_refused("cpu")

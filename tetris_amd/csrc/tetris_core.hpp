@@ -880,7 +880,7 @@ TET_HD void env_step(W (&col)[C], uint64_t& meta, int action, bool use_policy, c
   heights_of<W, C>(col, h);
   if ((TET_ABLATE & 1) || !cfg.compute_obs) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) out.obs[i] = (float)h[i];
+    for (int i = 0; i < 8; ++i) out.obs[i] = (float)h[i < C ? i : C - 1];  // placeholder: obs is not stored
   } else
   bcts_features<W, C, NCH, CR>(col, h, R, hole_lut, a, oH, eroded, k, out.obs);  // game.py:91
   if (cfg.has_direct_by) {

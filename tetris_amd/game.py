@@ -160,6 +160,8 @@ class Tetris:
 
     # ------------------------------------------------------------------ game.py:94-100
     def is_game_over(self, state):
+        if np.any(np.asarray(state.representation)[self.num_rows:]):
+            return True  # a terminal State (cells in the overflow rows): every placement on it stays terminal
         sc = self._get_scratch()
         self._push_state(sc, state, self.current_tetromino)
         return int(sc.n_valid[0]) == 0

@@ -294,10 +294,18 @@ class VecTetris:
 
     def set_boards(self, cells, piece=None):
         """Overwrite the boards (int8 [B, R+4, C]) and optionally the current
-        pieces (list indices [B]); the valid masks are recomputed."""
+        pieces (list indices [B]); the valid masks are recomputed.
+
+        The boards must be states a game can be in: a board with a cell in the overflow rows
+        (row >= num_rows) is a terminal State (state.py:33-36), which the reference never steps
+        from (game.py:69 keeps non-terminal afterstates only); the kernels' placement mask and
+        10-row feature tables assume there is none, so such a board is refused here."""
         cells = torch.as_tensor(cells, device=self.device).to(torch.int8).contiguous()
         if cells.shape != (self.batch_size, self.stored_rows, self.num_columns):
             raise ValueError("cells must be [B, num_rows + 4, num_columns]")
+        if bool((cells[:, self.num_rows:, :] != 0).any()):
+            raise ValueError("boards with cells in the overflow rows (row >= num_rows) are terminal states "
+                             "and cannot be set as current boards")
         rc = self._lib.encode(ctypes.byref(self.desc), _ptr(cells), _ptr(self.cols), self.batch_size,
                               self._hip_stream())
         self._lib.check(rc, "tetris_hip_encode")
