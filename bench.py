@@ -94,6 +94,10 @@ def main():
     ap.add_argument("--fuse", type=int, default=1,
                     help="env-steps per kernel launch (tetris_hip_step_many: boards stay in registers between the "
                          "fused steps, every step's outputs are still written); 1 = one launch per step (headline)")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="hold the batch of one GPU as this many env shards, each stepped on its own HIP stream "
+                         "(as the shards of several GPUs are): the tail of one shard's launch overlaps the ramp of "
+                         "the next.  1 = one launch over the whole batch per step (headline)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
 
@@ -115,8 +119,16 @@ def main():
     from tetris_amd.distributed import DoneGather
 
     B = args.batch
-    env = VecTetris(args.columns, args.rows, B, device=dev, pieces=args.pieces, auto_reset=True, seed=0,
-                    env_offset=rank * B, compute_obs=not args.no_obs)
+    S = max(1, args.streams)
+    if B % S:
+        raise SystemExit("--batch must be a multiple of --streams")
+    streams = [torch.cuda.current_stream(dev)] if S == 1 else [torch.cuda.Stream(dev) for _ in range(S)]
+    envs = []
+    for k in range(S):  # shard k = global envs [rank*B + k*B/S, ...): the same pieces as one big batch draws
+        with torch.cuda.stream(streams[k]):
+            envs.append(VecTetris(args.columns, args.rows, B // S, device=dev, pieces=args.pieces, auto_reset=True,
+                                  seed=0, env_offset=rank * B + k * (B // S), compute_obs=not args.no_obs))
+    env = envs[0]
     gather = DoneGather(B)
 
     def barrier():
@@ -125,18 +137,33 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    def all_totals():
+        for st in streams[1:] if S > 1 else []:
+            torch.cuda.current_stream(dev).wait_stream(st)
+        if S > 1:
+            torch.cuda.current_stream(dev).wait_stream(streams[0])
+        return sum(e.totals() for e in envs)
+
     fuse = max(1, args.fuse)
     if args.steps % fuse or args.warmup % fuse:
         raise SystemExit("--steps and --warmup must be multiples of --fuse")
-    traj = [None]
+    traj = [None] * S
+
+    def shard_step(k):
+        if fuse == 1:
+            envs[k].step()  # action = None: uniform random valid action drawn inside the step kernel
+        else:  # `fuse` steps per launch, trajectory buffers reused
+            traj[k] = envs[k].step_many(fuse, out=traj[k])
 
     def one_step(t):
-        if fuse == 1:
-            env.step()  # action = None: uniform random valid action drawn inside the step kernel
+        if S == 1:
+            shard_step(0)
         else:
-            traj[0] = env.step_many(fuse, out=traj[0])  # `fuse` steps per launch, trajectory buffers reused
+            for k in range(S):
+                with torch.cuda.stream(streams[k]):
+                    shard_step(k)
         if world > 1 and (t + 1) % max(1, args.gather_every // fuse) == 0:
-            gather.gather_counters(env.totals())
+            gather.gather_counters(all_totals())
 
     for t in range(args.warmup // fuse):
         one_step(t)
@@ -145,33 +172,39 @@ def main():
     for t in range(args.steps // fuse):
         one_step(t)
     if world > 1:
-        gather.gather_bits(env.done)  # the done/reset gather over RCCL
+        for st in streams:
+            torch.cuda.current_stream(dev).wait_stream(st)
+        gather.gather_bits(env.done if S == 1 else torch.cat([e.done for e in envs]))  # the done/reset gather over RCCL
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    totals = gather.gather_counters(env.totals()).cpu().tolist()
+    totals = gather.gather_counters(all_totals()).cpu().tolist()
 
     # step-kernel time alone: HIP events on the launch stream (torch's current stream) around
     # runs of back-to-back launches; per-launch time = elapsed / launches (includes the ~1.5 us
     # inter-kernel gap, so it reads a few % above rocprofv3's kernel-only average)
+    # (with --streams S > 1 the bracket sits on shard 0's stream: it reads the period at which that
+    # stream's launches complete while the other shards' launches run beside them)
     n_rep, n_per = 8, 50
     k_ms = []
     for _ in range(n_rep):
         s_ev, e_ev = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        s_ev.record()
+        s_ev.record(streams[0])
         for _ in range(n_per):
             one_step(-2)
-        e_ev.record()
+        e_ev.record(streams[0])
         torch.cuda.synchronize(dev)
         k_ms.append(s_ev.elapsed_time(e_ev) / n_per)
     k_ms = sorted(k_ms)[len(k_ms) // 2]
-    env.check()
+    for e in envs:
+        e.check()
 
     if rank == 0:
         alg = algorithmic_bytes_per_env_step(args.columns, env.desc.word_bytes, not args.no_obs)
+        # S shard launches of B/S envs run beside each other during every period k_ms
         achieved = alg * B * fuse / (k_ms * 1e-3) / 1e9
         out = {
             "metric": "env-steps/sec",
@@ -189,12 +222,13 @@ def main():
             "config": {"workload": "%d envs/GPU x %d GPU, %dx%d board, pieces=%s, uniform random valid actions, "
                                    "in-kernel auto-reset, device bag seed 0" % (B, world, args.columns, args.rows,
                                                                                 args.pieces),
-                       "envs_per_gpu": B, "observation_output": not args.no_obs, "env_steps_per_launch": fuse, "board": "%dx%d" % (args.columns, args.rows), "pieces": args.pieces,
+                       "envs_per_gpu": B, "observation_output": not args.no_obs, "env_steps_per_launch": fuse,
+                       "streams_per_gpu": S, "board": "%dx%d" % (args.columns, args.rows), "pieces": args.pieces,
                        "sharding": "env-index ranges, no data-path collective; RCCL gathers done counters every "
                                    "%d steps + done bitmask at the end" % args.gather_every},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None if (args.no_obs or fuse > 1) else load_traffic(args.columns, args.rows, args.pieces, B),
+                         "traffic": None if (args.no_obs or fuse > 1 or S > 1) else load_traffic(args.columns, args.rows, args.pieces, B),
                          "kernel": "step_kernel" if fuse == 1 else "step_many_kernel (%d steps per launch)" % fuse, "kernel_ms": k_ms, "algorithmic_bytes_per_env_step": alg},
             "episodes": totals[1], "lines_cleared": totals[2],
         }

@@ -15,6 +15,10 @@ timeout -k 10 200 python3 bench.py --no-cpu-baseline --rows 40 > $OUT/bench_n1_1
 timeout -k 10 200 python3 bench.py --no-cpu-baseline --pieces standard7 > $OUT/bench_n1_10x20_standard7.json 2>/dev/null || exit 1
 timeout -k 10 200 python3 bench.py --no-cpu-baseline --no-obs > $OUT/bench_n1_10x20_no_obs.json 2>/dev/null || exit 1
 timeout -k 10 200 python3 bench.py --no-cpu-baseline --fuse 20 --steps 1000 --warmup 100 > $OUT/bench_n1_10x20_fuse20.json 2>/dev/null || exit 1
+# two env shards per GPU on two HIP streams (the tail of one launch overlaps the ramp of the other)
+timeout -k 10 200 python3 bench.py --no-cpu-baseline --streams 2 > $OUT/bench_n1_10x20_streams2.json 2>/dev/null || exit 1
+timeout -k 10 200 python3 bench.py --no-cpu-baseline --streams 2 --rows 40 > $OUT/bench_n1_10x40_streams2.json 2>/dev/null || exit 1
+timeout -k 10 200 python3 bench.py --no-cpu-baseline --streams 2 --fuse 20 --steps 1000 --warmup 100 > $OUT/bench_n1_10x20_streams2_fuse20.json 2>/dev/null || exit 1
 echo "bench done"
 
 # 2. kernel trace of the same bench command (per-kernel average duration)
