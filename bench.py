@@ -184,11 +184,11 @@ def main():
     totals = gather.gather_counters(all_totals()).cpu().tolist()
 
     # step-kernel time alone: HIP events on the launch stream (torch's current stream) around
-    # runs of back-to-back launches; per-launch time = elapsed / launches (includes the ~1.5 us
+    # runs of 200 back-to-back launches; per-launch time = elapsed / launches (includes the ~1.5 us
     # inter-kernel gap, so it reads a few % above rocprofv3's kernel-only average)
     # (with --streams S > 1 the bracket sits on shard 0's stream: it reads the period at which that
     # stream's launches complete while the other shards' launches run beside them)
-    n_rep, n_per = 8, 50
+    n_rep, n_per = 5, 200  # (long runs: the idle-queue start-up of a bracket is amortised over 200 launches)
     k_ms = []
     for _ in range(n_rep):
         s_ev, e_ev = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

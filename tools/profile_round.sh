@@ -48,5 +48,7 @@ echo "afterstates done"
 timeout -k 10 300 python3 tools/bench_policy.py > $OUT/policy_kernels_10x20.json 2>/dev/null || exit 1
 timeout -k 10 100 python3 tools/ubench/fill_bw.py > $OUT/ubench_fill_bw.txt 2>/dev/null || exit 1
 if [ -x build_variants/row_store ]; then timeout -k 10 60 ./build_variants/row_store > $OUT/ubench_row_store.txt 2>/dev/null || exit 1; fi
+timeout -k 10 100 python3 tools/launch_overhead.py > $OUT/host_launch_overhead.txt 2>/dev/null || exit 1
+timeout -k 10 100 python3 examples/example_play.py > $OUT/example_play.txt 2>/dev/null || exit 1
 echo "policy + ubench done"
 ls -la $OUT
