@@ -168,13 +168,6 @@ TET_HD int select_bit32(uint32_t v, int k) {
   if (k >= c) { pos += 1; }
   return pos;
 }
-TET_HD int select_bit(uint64_t x, int k) {
-  const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
-  const int c = popc(lo);
-  const bool up = k >= c;
-  return select_bit32(up ? hi : lo, up ? k - c : k) + (up ? 32 : 0);
-}
-
 // draw one piece from the bag with 16 random bits (bag <= 12 bits)
 TET_HD int bag_draw(uint32_t& bag, int n_pieces, uint32_t r16) {
   if (bag == 0) bag = (1u << n_pieces) - 1u;
@@ -273,11 +266,6 @@ TET_HD int row_of_slot(uint64_t mask, int kk, int c) {
   if (L) row += popc(mask_field<C>(mask, 0)) + popc(mask_field<C>(mask, 1));
   return row;
 }
-
-template <typename W, int C>
-struct Board {
-  W col[C];
-};
 
 template <typename W, int C>
 TET_HD void heights_of(const W (&col)[C], int (&h)[C]) {
