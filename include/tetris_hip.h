@@ -19,10 +19,12 @@
  *  - functions are re-entrant.
  *
  * Data layout (all [..] are element counts; B = batch)
- *  cols  : column bitboards, plane-major: cols[c*B + i] = column c of env i;
- *          bit r = cell (row r, column c), row 0 = bottom, rows 0..R+3 stored
- *          (game.py:56, state.py:27-30).  Word = uint32 if R+4 <= 31,
- *          uint64 if R+4 <= 63 (TetrisDesc.word_bytes).
+ *  cols  : column bitboards: bit r of a column = cell (row r, column c), row 0 =
+ *          bottom, rows 0..R+3 stored (game.py:56, state.py:27-30).  Word = uint32 if
+ *          R+4 <= 31, uint64 if R+4 <= 63 (TetrisDesc.word_bytes).  Stored plane-major,
+ *          word[tetris_hip_n_planes(desc)][B]: one plane per column, or -- when the
+ *          stored rows fit three quarters of the word -- the columns bit-packed four to
+ *          three words (see tetris_hip_n_planes below).
  *  meta  : uint64[B] per-env control word:
  *            bits  0-47 valid mask: four C-bit fields, field 2L + o (loop L,
  *                       orientation o of tetromino.py's enumeration), bit c = left
@@ -40,7 +42,7 @@
 extern "C" {
 #endif
 
-#define TETRIS_HIP_ABI_VERSION 3
+#define TETRIS_HIP_ABI_VERSION 4
 
 #define TETRIS_MAX_PIECES 12
 #define TETRIS_MAX_COLUMNS 10
@@ -82,6 +84,14 @@ typedef struct TetrisDesc {
  * [n_waves][4], zeroed by the caller; the totals are the column sums. */
 enum { TETRIS_STATUS_INVALID = 0, TETRIS_STATUS_EPISODES = 1, TETRIS_STATUS_LINES = 2, TETRIS_STATUS_STEPS = 3 };
 int64_t tetris_hip_status_words(int64_t B);
+
+/* Board storage.  `cols` is plane-major: word_bytes-wide words planes[p][env], p < n_planes.
+ * When the stored rows num_rows + 4 fit three quarters of the word (24 bits of 4-byte, 48 bits of
+ * 8-byte words: e.g. 10x20 and 10x40) the columns are 24- / 48-bit fields of one bit string, four
+ * columns per three words, and ten columns take eight planes; otherwise plane c = column c.  The
+ * caller allocates word_bytes * tetris_hip_n_planes(desc) * B bytes and treats them as opaque:
+ * tetris_hip_decode / tetris_hip_encode convert to and from the reference layout. */
+int tetris_hip_n_planes(const TetrisDesc* desc);
 
 int tetris_hip_version(void);
 const char* tetris_hip_error_string(int code);

@@ -24,6 +24,22 @@ const FeatureLut kFeatureLutHost = {{
 #include "../../tetris_amd/csrc/tetris_feature_lut.inc"
 }};
 const uint8_t* const kHoleLut = reinterpret_cast<const uint8_t*>(&kFeatureLutHost);
+
+// boards in memory: the library's own packed / unpacked plane format (tet::board_packed)
+template <typename W, int C>
+void host_load(const W* planes, int64_t B, int64_t i, int R, W (&col)[C]) {
+  if (tet::board_packed((int)sizeof(W), R))
+    tet::load_board<W, C, true>(planes, B, i, col);
+  else
+    tet::load_board<W, C, false>(planes, B, i, col);
+}
+template <typename W, int C>
+void host_store(W* planes, int64_t B, int64_t i, int R, const W (&col)[C]) {
+  if (tet::board_packed((int)sizeof(W), R))
+    tet::store_board<W, C, true>(planes, B, i, col);
+  else
+    tet::store_board<W, C, false>(planes, B, i, col);
+}
 // the 10-row-chunk set the stepping kernels use on u32 boards of up to 20 rows (LaunchStep)
 struct alignas(16) FeatureLut10 {
   uint8_t bytes[tet::kFeatureLut10Bytes];
@@ -53,7 +69,7 @@ void step_impl(const TetrisDesc* desc, void* cols_, uint64_t* meta, const int32_
   W* cols = static_cast<W*>(cols_);
   for (int64_t i = 0; i < B; ++i) {
     W col[C];
-    for (int c = 0; c < C; ++c) col[c] = cols[(int64_t)c * B + i];
+    host_load<W, C>(cols, B, i, desc->num_rows, col);
     uint64_t m = meta[i];
     int draw = -1, draw_reset = -1, cur = 0;
     if (stream) {
@@ -76,7 +92,7 @@ void step_impl(const TetrisDesc* desc, void* cols_, uint64_t* meta, const int32_
                           (uint32_t)(env_offset + i), draw, draw_reset, out);
     if (action_out) action_out[i] = out.action;
     if (!out.invalid) {
-      for (int c = 0; c < C; ++c) cols[(int64_t)c * B + i] = col[c];
+      host_store<W, C>(cols, B, i, desc->num_rows, col);
       meta[i] = m;
       if (stream) cursor[i] = cur + 1 + ((out.done && auto_reset) ? 1 : 0);
     }
@@ -109,7 +125,10 @@ void reset_impl(const TetrisDesc* desc, void* cols_, uint64_t* meta, const uint8
   W* cols = static_cast<W*>(cols_);
   for (int64_t i = 0; i < B; ++i) {
     if (reset_mask && !reset_mask[i]) continue;
-    for (int c = 0; c < C; ++c) cols[(int64_t)c * B + i] = 0;
+    {
+      W zero[C] = {};
+      host_store<W, C>(cols, B, i, desc->num_rows, zero);
+    }
     uint32_t bag = init_bag ? 0u : tet::meta_bag(meta[i]);
     int piece;
     if (stream) {
@@ -135,7 +154,7 @@ void refresh_impl(const TetrisDesc* desc, const void* cols_, uint64_t* meta, uin
   for (int64_t i = 0; i < B; ++i) {
     W col[C];
     int h[C];
-    for (int c = 0; c < C; ++c) col[c] = cols[(int64_t)c * B + i];
+    host_load<W, C>(cols, B, i, desc->num_rows, col);
     tet::heights_of<W, C>(col, h);
     const int piece = tet::meta_piece(meta[i]);
     const uint64_t mask = tet::valid_mask<W, C>(col, h, tab.orient[piece], tab.fullmask[piece], desc->num_rows);
@@ -154,7 +173,7 @@ void after_impl(const TetrisDesc* desc, const void* cols_, const uint64_t* meta,
   for (int64_t i = 0; i < B; ++i) {
     W col[C];
     int h[C];
-    for (int c = 0; c < C; ++c) col[c] = cols[(int64_t)c * B + i];
+    host_load<W, C>(cols, B, i, desc->num_rows, col);
     tet::heights_of<W, C>(col, h);
     const int piece = tet::meta_piece(meta[i]);
     const uint64_t full = tab.fullmask[piece];
@@ -287,7 +306,7 @@ int tetris_host_policy_greedy(const TetrisDesc* desc, const void* cols_, const u
     const W* cols = static_cast<const W*>(cols_);
     for (int64_t i = 0; i < B; ++i) {
       W col[C];
-      for (int c = 0; c < C; ++c) col[c] = cols[(int64_t)c * B + i];
+      host_load<W, C>(cols, B, i, desc->num_rows, col);
       const int piece = tet::meta_piece(meta[i]);
       const uint64_t full = tab.fullmask[piece];
       const uint64_t valid = tet::meta_mask(meta[i]) & full;
@@ -330,7 +349,7 @@ int tetris_host_rollouts(const TetrisDesc* desc, const void* cols_, const uint64
     const int a_max = desc->a_max;
     for (int64_t i = 0; i < B; ++i) {
       W col[C];
-      for (int c = 0; c < C; ++c) col[c] = cols[(int64_t)c * B + i];
+      host_load<W, C>(cols, B, i, desc->num_rows, col);
       const int nv = tet::popc(tet::meta_mask(meta[i]));
       for (int a0 = 0; a0 < a_max; ++a0) {
         double mean = __builtin_nan("");
@@ -374,7 +393,7 @@ int tetris_host_step_many(const TetrisDesc* desc, void* cols_, uint64_t* meta, i
     W* cols = static_cast<W*>(cols_);
     for (int64_t i = 0; i < B; ++i) {
       W col[C];
-      for (int c = 0; c < C; ++c) col[c] = cols[(int64_t)c * B + i];
+      host_load<W, C>(cols, B, i, desc->num_rows, col);
       uint64_t m = meta[i];
       for (int k = 0; k < n_steps; ++k) {
         cfg.key_step = tet::hash_key(seed, (step_idx0 + k) * 4u + 0u);
@@ -422,13 +441,19 @@ int tetris_host_step_many(const TetrisDesc* desc, void* cols_, uint64_t* meta, i
           }
         }
       }
-      for (int c = 0; c < C; ++c) cols[(int64_t)c * B + i] = col[c];
+      host_store<W, C>(cols, B, i, desc->num_rows, col);
       meta[i] = m;
     }
   });
 }
 
 int tetris_host_version(void) { return TETRIS_HIP_ABI_VERSION; }
+
+int tetris_host_n_planes(const TetrisDesc* desc) {
+  const int rc = tet::check_desc(desc);
+  if (rc) return rc;
+  return tet::n_planes(desc->num_columns, tet::board_packed(desc->word_bytes, desc->num_rows));
+}
 
 int64_t tetris_host_status_words(int64_t B) { return B <= 0 ? 0 : 4 * (((B + 1023) / 1024) * 16); }
 
@@ -441,10 +466,12 @@ int tetris_host_decode(const TetrisDesc* desc, const void* cols, int8_t* cells, 
                        void* unused) {
   (void)unused;
   const int C = desc->num_columns, rows = desc->num_rows + 4;
+  const bool packed = tet::board_packed(desc->word_bytes, desc->num_rows);
   for (int64_t i = 0; i < B; ++i)
     for (int c = 0; c < C; ++c) {
-      uint64_t x = desc->word_bytes == 4 ? static_cast<const uint32_t*>(cols)[(int64_t)c * B + i]
-                                         : static_cast<const uint64_t*>(cols)[(int64_t)c * B + i];
+      uint64_t x = desc->word_bytes == 4
+                       ? tet::load_column_rt<uint32_t>(static_cast<const uint32_t*>(cols), B, i, c, packed)
+                       : tet::load_column_rt<uint64_t>(static_cast<const uint64_t*>(cols), B, i, c, packed);
       if (heights) heights[i * C + c] = tet::bitlen(x);
       if (cells)
         for (int r = 0; r < rows; ++r) cells[(i * rows + r) * C + c] = (int8_t)((x >> r) & 1);
@@ -455,13 +482,21 @@ int tetris_host_decode(const TetrisDesc* desc, const void* cols, int8_t* cells, 
 int tetris_host_encode(const TetrisDesc* desc, const int8_t* cells, void* cols, int64_t B, void* unused) {
   (void)unused;
   const int C = desc->num_columns, rows = desc->num_rows + 4;
-  for (int64_t i = 0; i < B; ++i)
+  const bool packed = tet::board_packed(desc->word_bytes, desc->num_rows);
+  for (int64_t i = 0; i < B; ++i) {
+    uint64_t col[tet::kMaxCols];
+    uint32_t col32[tet::kMaxCols];
     for (int c = 0; c < C; ++c) {
       uint64_t x = 0;
       for (int r = 0; r < rows; ++r) x |= (uint64_t)(cells[(i * rows + r) * C + c] != 0) << r;
-      if (desc->word_bytes == 4) static_cast<uint32_t*>(cols)[(int64_t)c * B + i] = (uint32_t)x;
-      else static_cast<uint64_t*>(cols)[(int64_t)c * B + i] = x;
+      col[c] = x;
+      col32[c] = (uint32_t)x;
     }
+    if (desc->word_bytes == 4)
+      tet::store_columns_rt<uint32_t>(static_cast<uint32_t*>(cols), B, i, col32, C, packed);
+    else
+      tet::store_columns_rt<uint64_t>(static_cast<uint64_t*>(cols), B, i, col, C, packed);
+  }
   return 0;
 }
 

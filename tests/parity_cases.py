@@ -116,7 +116,7 @@ def golden_trajectories_replay(device, orc, golden_dir):
                         np.testing.assert_array_equal(f[i].cpu().numpy(), g["s%d_after_valid" % s][t][:env.a_max])
                         np.testing.assert_array_equal(fa[i].cpu().numpy(), g["s%d_after_all" % s][t][:env.a_max])
             obs, rew, done, lines = env.step(torch.from_numpy(act))
-            cols = env.cols.cpu().numpy().astype(np.uint64).T  # [B, C]
+            cols = env.columns().cpu().numpy().astype(np.uint64).T  # [B, C]
             for i, s in enumerate(seeds):
                 np.testing.assert_array_equal(obs[i].cpu().numpy(), g["s%d_obs" % s][t])
                 assert int(rew[i]) == g["s%d_reward" % s][t] and bool(done[i]) == bool(g["s%d_done" % s][t])
@@ -190,9 +190,10 @@ def full_size_properties(device, B=1 << 20, steps=60, R=20):
     st = env.stats()
     assert st["invalid"] == 0 and st["steps"] == steps * B and st["episodes"] > 0
     # no full row survives in any board
-    full = env.cols[0]
+    cols = env.columns()
+    full = cols[0]
     for c in range(1, 10):
-        full = full & env.cols[c]
+        full = full & cols[c]
     assert not full.any()
 
 

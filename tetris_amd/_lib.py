@@ -9,7 +9,7 @@ import os
 from . import build as _build
 
 MAX_PIECES = 12
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class TetrisDesc(ctypes.Structure):
@@ -41,6 +41,7 @@ SIGNATURES = {
     "tetris_hip_desc_init": [_dp, _i32, _i32, _vp, _i32, _vp],
     "tetris_hip_n_placements": [_i32, _i32],
     "tetris_hip_status_words": [_i64],
+    "tetris_hip_n_planes": [_dp],
     "tetris_hip_reset": [_dp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _u64, _u64, _i64, _i64, _vp],
     "tetris_hip_step": [_dp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _u64, _u64,
                         _i64, _i64, _vp],

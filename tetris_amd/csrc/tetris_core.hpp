@@ -98,6 +98,105 @@ TET_HD Orient unpack_orient(uint32_t d) {
   return o;
 }
 
+// ---- storage of a board in HBM ---------------------------------------------
+// Plane-major words `planes[p][env]`.  Unpacked: plane c = column c.  Packed (chosen whenever the
+// stored rows R + 4 fit three quarters of the word: 24 bits of u32, 48 of u64): the columns are
+// F = 24 / 48-bit fields of one bit string, four columns per three words, so ten columns take
+// eight planes instead of ten -- a fifth fewer board bytes per env-step on the paper's 10x20 and
+// 10x40 boards.  board_packed() is a function of the descriptor alone: every kernel, the host
+// harness and the Python host agree on it through tetris_hip_n_planes().
+#ifndef TET_NO_PACK
+#define TET_NO_PACK 0   // 1: one plane per column always (A/B timing builds)
+#endif
+TET_HD constexpr bool board_packed(int word_bytes, int num_rows) { return !TET_NO_PACK && num_rows + 4 <= 6 * word_bytes; }
+TET_HD constexpr int n_planes(int C, bool packed) { return packed ? (C / 4) * 3 + ((C % 4) * 3 + 3) / 4 : C; }
+
+template <typename W, int C, bool PACK>
+TET_HD void unpack_board(const W (&w)[n_planes(C, PACK)], W (&col)[C]) {
+  if (!PACK) {
+#pragma unroll
+    for (int c = 0; c < C; ++c) col[c] = w[c < n_planes(C, PACK) ? c : 0];
+    return;
+  }
+  constexpr int Wb = 8 * (int)sizeof(W), F = Wb * 3 / 4, P = n_planes(C, PACK);
+  const W M = (W)(((W)1 << F) - 1);
+#pragma unroll
+  for (int g = 0; 4 * g < C; ++g) {
+    const int b = 3 * g, c0 = 4 * g;
+    const W w0 = w[b], w1 = w[b + 1 < P ? b + 1 : b], w2 = w[b + 2 < P ? b + 2 : b];
+    col[c0] = (W)(w0 & M);
+    if (c0 + 1 < C) col[c0 + 1] = (W)(((w0 >> F) | (w1 << (Wb - F))) & M);
+    if (c0 + 2 < C) col[c0 + 2] = (W)(((w1 >> (2 * F - Wb)) | (w2 << (2 * Wb - 2 * F))) & M);
+    if (c0 + 3 < C) col[c0 + 3] = (W)(w2 >> (3 * F - 2 * Wb));
+  }
+}
+
+// (columns must fit F bits: boards of R + 4 <= F stored rows)
+template <typename W, int C, bool PACK>
+TET_HD void pack_board(const W (&col)[C], W (&w)[n_planes(C, PACK)]) {
+  if (!PACK) {
+#pragma unroll
+    for (int c = 0; c < n_planes(C, PACK); ++c) w[c] = col[c < C ? c : 0];
+    return;
+  }
+  constexpr int Wb = 8 * (int)sizeof(W), F = Wb * 3 / 4, P = n_planes(C, PACK);
+#pragma unroll
+  for (int g = 0; 4 * g < C; ++g) {
+    const int b = 3 * g, c0 = 4 * g;
+    const W x0 = col[c0], x1 = c0 + 1 < C ? col[c0 + 1 < C ? c0 + 1 : c0] : (W)0;
+    const W x2 = c0 + 2 < C ? col[c0 + 2 < C ? c0 + 2 : c0] : (W)0, x3 = c0 + 3 < C ? col[c0 + 3 < C ? c0 + 3 : c0] : (W)0;
+    w[b] = (W)(x0 | (x1 << F));
+    if (b + 1 < P) w[b + 1 < P ? b + 1 : b] = (W)((x1 >> (Wb - F)) | (x2 << (2 * F - Wb)));
+    if (b + 2 < P) w[b + 2 < P ? b + 2 : b] = (W)((x2 >> (2 * Wb - 2 * F)) | (x3 << (3 * F - 2 * Wb)));
+  }
+}
+
+// the same for memory: planes[p * B + i]
+template <typename W, int C, bool PACK>
+TET_HD void load_board(const W* planes, int64_t B, int64_t i, W (&col)[C]) {
+  W w[n_planes(C, PACK)];
+#pragma unroll
+  for (int p = 0; p < n_planes(C, PACK); ++p) w[p] = planes[(int64_t)p * B + i];
+  unpack_board<W, C, PACK>(w, col);
+}
+template <typename W, int C, bool PACK>
+TET_HD void store_board(W* planes, int64_t B, int64_t i, const W (&col)[C]) {
+  W w[n_planes(C, PACK)];
+  pack_board<W, C, PACK>(col, w);
+#pragma unroll
+  for (int p = 0; p < n_planes(C, PACK); ++p) planes[(int64_t)p * B + i] = w[p];
+}
+
+// run-time column count (codec kernels): column c of env i / all planes of env i from a column array
+template <typename W>
+TET_HD W load_column_rt(const W* planes, int64_t B, int64_t i, int c, bool packed) {
+  if (!packed) return planes[(int64_t)c * B + i];
+  constexpr int Wb = 8 * (int)sizeof(W), F = Wb * 3 / 4;
+  const W M = (W)(((W)1 << F) - 1);
+  const int b = 3 * (c >> 2), k = c & 3;
+  const W lo = planes[(int64_t)(b + (k == 0 ? 0 : k - 1)) * B + i];
+  if (k == 0) return (W)(lo & M);
+  if (k == 3) return (W)(lo >> (3 * F - 2 * Wb));
+  const W hi = planes[(int64_t)(b + k) * B + i];
+  return k == 1 ? (W)(((lo >> F) | (hi << (Wb - F))) & M) : (W)(((lo >> (2 * F - Wb)) | (hi << (2 * Wb - 2 * F))) & M);
+}
+template <typename W>
+TET_HD void store_columns_rt(W* planes, int64_t B, int64_t i, const W* col, int C, bool packed) {
+  if (!packed) {
+    for (int c = 0; c < C; ++c) planes[(int64_t)c * B + i] = col[c];
+    return;
+  }
+  constexpr int Wb = 8 * (int)sizeof(W), F = Wb * 3 / 4;
+  const int P = n_planes(C, true);
+  for (int p = 0; p < P; ++p) {
+    const int c0 = 4 * (p / 3), q = p % 3;
+    const W a = c0 + q < C ? col[c0 + q] : (W)0, b = c0 + q + 1 < C ? col[c0 + q + 1] : (W)0;
+    const W v = q == 0 ? (W)(a | (b << F))
+                       : (q == 1 ? (W)((a >> (Wb - F)) | (b << (2 * F - Wb))) : (W)((a >> (2 * Wb - 2 * F)) | (b << (3 * F - 2 * Wb))));
+    planes[(int64_t)p * B + i] = v;
+  }
+}
+
 // ---- meta word ------------------------------------------------------------
 // bits 0-47  valid mask: four C-bit fields, field k = 2L + o (loop L, orientation o of
 //            tetromino.py's enumeration), bit c of a field = left column c.  The reference

@@ -138,6 +138,15 @@ __device__ __forceinline__ void st_off(T* base, uint32_t byte_off, T v) {
   *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + byte_off) = v;
 }
 
+// The board of env i goes back to its planes (packed storage: tet::pack_board).
+template <typename W, int C, bool PACK>
+__device__ __forceinline__ void store_planes(const StepParams& p, uint32_t i, const W (&col)[C]) {
+  W w[tet::n_planes(C, PACK)];
+  tet::pack_board<W, C, PACK>(col, w);
+#pragma unroll
+  for (int q = 0; q < tet::n_planes(C, PACK); ++q) st_off(static_cast<W*>(p.plane[q]), i * (uint32_t)sizeof(W), w[q]);
+}
+
 // Everything one lane reads for one env.
 template <typename W, int C>
 struct StepInputs {
@@ -148,12 +157,13 @@ struct StepInputs {
   uint4 status;
 };
 
-template <typename W, int C>
+template <typename W, int C, bool PACK>
 __device__ __forceinline__ void load_inputs(const StepParams& p, uint32_t i, StepInputs<W, C>& in) {
-  const W* cols = static_cast<const W*>(p.cols);
   const uint32_t ii = i < p.B ? i : 0;
+  W w[tet::n_planes(C, PACK)];
 #pragma unroll
-  for (int c = 0; c < C; ++c) in.col[c] = ld_off(static_cast<const W*>(p.plane[c]), ii * (uint32_t)sizeof(W));
+  for (int q = 0; q < tet::n_planes(C, PACK); ++q) w[q] = ld_off(static_cast<const W*>(p.plane[q]), ii * (uint32_t)sizeof(W));
+  tet::unpack_board<W, C, PACK>(w, in.col);
   in.meta = ld_off(p.meta, ii * 8u);
   in.action = p.action ? ld_off(p.action, ii * 4u) : -1;
   in.draw = -1;
@@ -187,8 +197,9 @@ __global__ __launch_bounds__(step_block<W>(), (step_waves<W, CR>())) void step_k
   const bool live = i < p.B;
   // Issue every global load of this lane first (board, meta, action, counters, its share of the
   // two tables) so that one memory latency covers them all; only then fill LDS and barrier.
+  constexpr bool PACK = NCH != 0 && !TET_NO_PACK;  // the launchers pick a counted-chunk variant exactly for packed boards
   StepInputs<W, C> in;
-  load_inputs<W, C>(p, i, in);
+  load_inputs<W, C, PACK>(p, i, in);
   {
     constexpr int kLutVecs = tet::LutLayout<CR>::kBytes / 16, kLutPerLane = (kLutVecs + kBlock - 1) / kBlock;
     const uint4* lsrc = feature_lut_src<CR>();
@@ -227,8 +238,7 @@ __global__ __launch_bounds__(step_block<W>(), (step_waves<W, CR>())) void step_k
       st_off(o4, i * 32u + 16u, make_float4(out.obs[4], out.obs[5], out.obs[6], out.obs[7]));
     }
     if (!invalid) {
-#pragma unroll
-      for (int c = 0; c < C; ++c) st_off(static_cast<W*>(p.plane[c]), i * (uint32_t)sizeof(W), in.col[c]);
+      store_planes<W, C, PACK>(p, i, in.col);
       st_off(p.meta, i * 8u, in.meta);
       done = out.done;
       lines = out.lines;
@@ -281,8 +291,9 @@ __global__ __launch_bounds__(step_block<W>(), (POLICY == 0 ? step_waves<W, CR>()
   W (&lane_cols)[C][kBlock] = lds.lane_cols;
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
   const bool live = i < p.B;
+  constexpr bool PACK = NCH != 0 && !TET_NO_PACK;
   StepInputs<W, C> in;
-  load_inputs<W, C>(p, i, in);
+  load_inputs<W, C, PACK>(p, i, in);
   stage_hole_lut<CR>(hole_lut);
   stage_table(tab, p.tab);
   unsigned n_inv = 0, n_done = 0, n_lines = 0, n_steps = 0;
@@ -340,8 +351,7 @@ __global__ __launch_bounds__(step_block<W>(), (POLICY == 0 ? step_waves<W, CR>()
     n_steps += wave_sum(1, (live && !invalid) ? 1 : 0);
   }
   if (live) {
-#pragma unroll
-    for (int c = 0; c < C; ++c) st_off(static_cast<W*>(p.plane[c]), i * (uint32_t)sizeof(W), in.col[c]);
+    store_planes<W, C, PACK>(p, i, in.col);
     st_off(p.meta, i * 8u, in.meta);
   }
   if (p.status && (threadIdx.x & 63) == 0) {
@@ -367,11 +377,12 @@ struct ResetParams {
   int64_t env_offset;
   int32_t init_bag;
   int32_t n_pieces;
+  int32_t R;
   uint32_t key;
   SetTable tab;
 };
 
-template <typename W, int C>
+template <typename W, int C, bool PACK>
 __global__ __launch_bounds__(kBlock) void reset_kernel(const ResetParams p) {
   __shared__ SetTable tab;
   stage_table(tab, p.tab);
@@ -380,7 +391,7 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const ResetParams p) {
   if (p.reset_mask && !p.reset_mask[i]) return;
   W* cols = static_cast<W*>(p.cols);
 #pragma unroll
-  for (int c = 0; c < C; ++c) cols[(int64_t)c * p.B + i] = 0;  // game.py:55-58
+  for (int q = 0; q < tet::n_planes(C, PACK); ++q) cols[(int64_t)q * p.B + i] = 0;  // game.py:55-58
   uint32_t bag = p.init_bag ? 0u : tet::meta_bag(p.meta[i]);
   int piece;
   if (p.stream) {
@@ -406,7 +417,7 @@ struct RefreshParams {
   SetTable tab;
 };
 
-template <typename W, int C>
+template <typename W, int C, bool PACK>
 __global__ __launch_bounds__(kBlock) void refresh_kernel(const RefreshParams p) {
   __shared__ SetTable tab;
   stage_table(tab, p.tab);
@@ -415,8 +426,7 @@ __global__ __launch_bounds__(kBlock) void refresh_kernel(const RefreshParams p) 
   const W* cols = static_cast<const W*>(p.cols);
   W col[C];
   int h[C];
-#pragma unroll
-  for (int c = 0; c < C; ++c) col[c] = cols[(int64_t)c * p.B + i];
+  tet::load_board<W, C, PACK>(cols, p.B, i, col);
   tet::heights_of<W, C>(col, h);
   const uint64_t meta = p.meta[i];
   const int piece = tet::meta_piece(meta);
@@ -487,8 +497,7 @@ __global__ __launch_bounds__(kBlock, TET_AFTER_WAVES) void afterstates_kernel(co
   const int64_t i = live ? i0 : p.B - 1;  // lanes past the end keep pace on the last env and store nothing
   const W* cols = static_cast<const W*>(p.cols);
   W col[C];
-#pragma unroll
-  for (int c = 0; c < C; ++c) col[c] = cols[(int64_t)c * p.B + i];
+  tet::load_board<W, C, (NCH != 0 && !TET_NO_PACK)>(cols, p.B, i, col);
   const uint64_t meta = p.meta[i];
   const int piece = tet::meta_piece(meta);
   const uint64_t full = tab.fullmask[piece];
@@ -559,8 +568,7 @@ __global__ __launch_bounds__(kBlock) void greedy_kernel(const GreedyParams p) {
   if (i >= p.B) return;
   const W* cols = static_cast<const W*>(p.cols);
   W col[C];
-#pragma unroll
-  for (int c = 0; c < C; ++c) col[c] = cols[(int64_t)c * p.B + i];
+  tet::load_board<W, C, (NCH != 0 && !TET_NO_PACK)>(cols, p.B, i, col);
   const uint64_t meta = p.meta[i];
   const int piece = tet::meta_piece(meta);
   const uint64_t full = tab.fullmask[piece];
@@ -619,8 +627,7 @@ __global__ __launch_bounds__(kBlock) void rollouts_kernel(const RolloutParams p)
   const int a0 = (int)(id - i * p.a_max);
   const W* cols = static_cast<const W*>(p.cols);
   W col[C];
-#pragma unroll
-  for (int c = 0; c < C; ++c) col[c] = cols[(int64_t)c * p.B + i];
+  tet::load_board<W, C, (NCH != 0 && !TET_NO_PACK)>(cols, p.B, i, col);
   const uint64_t meta = p.meta[i];
   const int nv = tet::popc(tet::meta_mask(meta));
   double mean = __longlong_as_double(0x7FF8000000000000ll);  // NaN: not an action of this env
@@ -647,11 +654,12 @@ __global__ __launch_bounds__(kBlock) void policy_random_kernel(const uint8_t* __
 
 template <typename W>
 __global__ __launch_bounds__(kBlock) void decode_kernel(const W* __restrict__ cols, int8_t* __restrict__ cells,
-                                                        int32_t* __restrict__ heights, int C, int rows, int64_t B) {
+                                                        int32_t* __restrict__ heights, int C, int rows, int64_t B,
+                                                        bool packed) {
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= B) return;
   for (int c = 0; c < C; ++c) {
-    const W x = cols[(int64_t)c * B + i];
+    const W x = tet::load_column_rt<W>(cols, B, i, c, packed);
     if (heights) heights[i * C + c] = tet::bitlen(x);
     if (cells)
       for (int r = 0; r < rows; ++r) cells[(i * rows + r) * C + c] = (int8_t)((x >> r) & 1);
@@ -660,14 +668,16 @@ __global__ __launch_bounds__(kBlock) void decode_kernel(const W* __restrict__ co
 
 template <typename W>
 __global__ __launch_bounds__(kBlock) void encode_kernel(const int8_t* __restrict__ cells, W* __restrict__ cols,
-                                                        int C, int rows, int64_t B) {
+                                                        int C, int rows, int64_t B, bool packed) {
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= B) return;
+  W col[tet::kMaxCols];
   for (int c = 0; c < C; ++c) {
     W x = 0;
     for (int r = 0; r < rows; ++r) x |= (W)(cells[(i * rows + r) * C + c] != 0) << r;
-    cols[(int64_t)c * B + i] = x;
+    col[c] = x;
   }
+  tet::store_columns_rt<W>(cols, B, i, col, C, packed);
 }
 
 // ---- dispatch on (word, C) -------------------------------------------------------
@@ -692,67 +702,71 @@ int dispatch(const TetrisDesc* d, const P& p, hipStream_t s) {
   return (int)hipGetLastError();
 }
 
+// Kernel variant of a geometry.  Packed boards (tet::board_packed: stored rows within three
+// quarters of the word) always run the variants with a compile-time chunk count -- NCH = 2 on u32,
+// 4 on u64 -- and those variants read / write the packed planes; everything else is NCH = 0 on
+// one plane per column.
+template <typename W>
+inline bool packed_geometry(int R) { return R + 4 <= 6 * (int)sizeof(W); }  // == tet::board_packed (TET_NO_PACK builds keep the variant choice)
+template <typename W>
+constexpr int packed_chunks() { return sizeof(W) == 4 ? 2 : 4; }
+
 template <typename W, int C>
 struct LaunchStep {
   static void run(const StepParams& p, hipStream_t s) {
     // a step only evaluates the features of a NON-terminal board (cells below row R): up to R = 20
     // (u32) two 10-row chunks cover it, up to R = 40 (u64) four, and the tables are the 7 KiB
-    // set; otherwise 12-row chunks, counted at compile time for the common geometries
-    const int stored = p.cfg.R + 4;
-    if (sizeof(W) == 4 && p.cfg.R <= 20 && TET_LUT10)
-      hipLaunchKernelGGL((step_kernel<W, C, 2, 10>), step_grid<W>(p.B), dim3(step_block<W>()), 0, s, p);
-    else if (sizeof(W) == 8 && p.cfg.R <= 40 && TET_LUT10)  // four 10-row chunks: 10x40 (BASELINE config 5)
-      hipLaunchKernelGGL((step_kernel<W, C, 4, 10>), step_grid<W>(p.B), dim3(step_block<W>()), 0, s, p);
-    else if (sizeof(W) == 4 && stored <= 24)
-      hipLaunchKernelGGL((step_kernel<W, C, 2, 12>), step_grid<W>(p.B), dim3(step_block<W>()), 0, s, p);
-    else if (sizeof(W) == 8 && stored > 36 && stored <= 48)
-      hipLaunchKernelGGL((step_kernel<W, C, 4, 12>), step_grid<W>(p.B), dim3(step_block<W>()), 0, s, p);
-    else
+    // set; otherwise 12-row chunks
+    constexpr int N = packed_chunks<W>();
+    if (!packed_geometry<W>(p.cfg.R))
       hipLaunchKernelGGL((step_kernel<W, C, 0, 12>), step_grid<W>(p.B), dim3(step_block<W>()), 0, s, p);
+    else if (p.cfg.R <= 10 * N && TET_LUT10)
+      hipLaunchKernelGGL((step_kernel<W, C, N, 10>), step_grid<W>(p.B), dim3(step_block<W>()), 0, s, p);
+    else
+      hipLaunchKernelGGL((step_kernel<W, C, N, 12>), step_grid<W>(p.B), dim3(step_block<W>()), 0, s, p);
   }
 };
 template <typename W, int C>
 struct LaunchStepMany {
   static void run(const StepManyParams& q, hipStream_t s) {
-    const int stored = q.one.cfg.R + 4;
-    if (q.policy == 1 && sizeof(W) == 4 && stored <= 24)
-      hipLaunchKernelGGL((step_many_kernel<W, C, 2, 1, 12>), step_grid<W>(q.one.B), dim3(step_block<W>()), 0, s, q);
-    else if (q.policy == 1 && sizeof(W) == 8 && stored > 36 && stored <= 48)
-      hipLaunchKernelGGL((step_many_kernel<W, C, 4, 1, 12>), step_grid<W>(q.one.B), dim3(step_block<W>()), 0, s, q);
+    constexpr int N = packed_chunks<W>();
+    const int R = q.one.cfg.R;
+    const bool packed = packed_geometry<W>(R);
+    if (q.policy == 1 && packed)
+      hipLaunchKernelGGL((step_many_kernel<W, C, N, 1, 12>), step_grid<W>(q.one.B), dim3(step_block<W>()), 0, s, q);
     else if (q.policy == 1)
       hipLaunchKernelGGL((step_many_kernel<W, C, 0, 1, 12>), step_grid<W>(q.one.B), dim3(step_block<W>()), 0, s, q);
-    else if (sizeof(W) == 4 && q.one.cfg.R <= 20 && TET_LUT10)
-      hipLaunchKernelGGL((step_many_kernel<W, C, 2, 0, 10>), step_grid<W>(q.one.B), dim3(step_block<W>()), 0, s, q);
-    else if (sizeof(W) == 8 && q.one.cfg.R <= 40 && TET_LUT10)
-      hipLaunchKernelGGL((step_many_kernel<W, C, 4, 0, 10>), step_grid<W>(q.one.B), dim3(step_block<W>()), 0, s, q);
-    else if (sizeof(W) == 4 && stored <= 24)
-      hipLaunchKernelGGL((step_many_kernel<W, C, 2, 0, 12>), step_grid<W>(q.one.B), dim3(step_block<W>()), 0, s, q);
-    else if (sizeof(W) == 8 && stored > 36 && stored <= 48)
-      hipLaunchKernelGGL((step_many_kernel<W, C, 4, 0, 12>), step_grid<W>(q.one.B), dim3(step_block<W>()), 0, s, q);
-    else
+    else if (!packed)
       hipLaunchKernelGGL((step_many_kernel<W, C, 0, 0, 12>), step_grid<W>(q.one.B), dim3(step_block<W>()), 0, s, q);
+    else if (R <= 10 * N && TET_LUT10)
+      hipLaunchKernelGGL((step_many_kernel<W, C, N, 0, 10>), step_grid<W>(q.one.B), dim3(step_block<W>()), 0, s, q);
+    else
+      hipLaunchKernelGGL((step_many_kernel<W, C, N, 0, 12>), step_grid<W>(q.one.B), dim3(step_block<W>()), 0, s, q);
   }
 };
 template <typename W, int C>
 struct LaunchReset {
   static void run(const ResetParams& p, hipStream_t s) {
-    hipLaunchKernelGGL((reset_kernel<W, C>), grid_for(p.B), dim3(kBlock), 0, s, p);
+    if (tet::board_packed((int)sizeof(W), p.R))
+      hipLaunchKernelGGL((reset_kernel<W, C, true>), grid_for(p.B), dim3(kBlock), 0, s, p);
+    else
+      hipLaunchKernelGGL((reset_kernel<W, C, false>), grid_for(p.B), dim3(kBlock), 0, s, p);
   }
 };
 template <typename W, int C>
 struct LaunchRefresh {
   static void run(const RefreshParams& p, hipStream_t s) {
-    hipLaunchKernelGGL((refresh_kernel<W, C>), grid_for(p.B), dim3(kBlock), 0, s, p);
+    if (tet::board_packed((int)sizeof(W), p.R))
+      hipLaunchKernelGGL((refresh_kernel<W, C, true>), grid_for(p.B), dim3(kBlock), 0, s, p);
+    else
+      hipLaunchKernelGGL((refresh_kernel<W, C, false>), grid_for(p.B), dim3(kBlock), 0, s, p);
   }
 };
 template <typename W, int C>
 struct LaunchRollouts {
   static void run(const RolloutParams& p, hipStream_t s) {
-    const int stored = p.R + 4;
-    if (sizeof(W) == 4 && stored <= 24)
-      hipLaunchKernelGGL((rollouts_kernel<W, C, 2>), grid_for(p.B * p.a_max), dim3(kBlock), 0, s, p);
-    else if (sizeof(W) == 8 && stored > 36 && stored <= 48)
-      hipLaunchKernelGGL((rollouts_kernel<W, C, 4>), grid_for(p.B * p.a_max), dim3(kBlock), 0, s, p);
+    if (packed_geometry<W>(p.R))
+      hipLaunchKernelGGL((rollouts_kernel<W, C, packed_chunks<W>()>), grid_for(p.B * p.a_max), dim3(kBlock), 0, s, p);
     else
       hipLaunchKernelGGL((rollouts_kernel<W, C, 0>), grid_for(p.B * p.a_max), dim3(kBlock), 0, s, p);
   }
@@ -760,11 +774,8 @@ struct LaunchRollouts {
 template <typename W, int C>
 struct LaunchGreedy {
   static void run(const GreedyParams& p, hipStream_t s) {
-    const int stored = p.R + 4;  // compile-time chunk counts as in LaunchStep
-    if (sizeof(W) == 4 && stored <= 24)
-      hipLaunchKernelGGL((greedy_kernel<W, C, 2>), grid_for(p.B), dim3(kBlock), 0, s, p);
-    else if (sizeof(W) == 8 && stored > 36 && stored <= 48)
-      hipLaunchKernelGGL((greedy_kernel<W, C, 4>), grid_for(p.B), dim3(kBlock), 0, s, p);
+    if (packed_geometry<W>(p.R))
+      hipLaunchKernelGGL((greedy_kernel<W, C, packed_chunks<W>()>), grid_for(p.B), dim3(kBlock), 0, s, p);
     else
       hipLaunchKernelGGL((greedy_kernel<W, C, 0>), grid_for(p.B), dim3(kBlock), 0, s, p);
   }
@@ -772,11 +783,8 @@ struct LaunchGreedy {
 template <typename W, int C>
 struct LaunchAfter {
   static void run(const AfterParams& p, hipStream_t s) {
-    const int stored = p.R + 4;
-    if (sizeof(W) == 4 && stored <= 24)
-      hipLaunchKernelGGL((afterstates_kernel<W, C, 2>), grid_for(p.B), dim3(kBlock), 0, s, p);
-    else if (sizeof(W) == 8 && stored > 36 && stored <= 48)
-      hipLaunchKernelGGL((afterstates_kernel<W, C, 4>), grid_for(p.B), dim3(kBlock), 0, s, p);
+    if (packed_geometry<W>(p.R))
+      hipLaunchKernelGGL((afterstates_kernel<W, C, packed_chunks<W>()>), grid_for(p.B), dim3(kBlock), 0, s, p);
     else
       hipLaunchKernelGGL((afterstates_kernel<W, C, 0>), grid_for(p.B), dim3(kBlock), 0, s, p);
   }
@@ -810,6 +818,12 @@ int tetris_hip_supported_columns(int32_t* out, int cap) {
   TET_COLUMNS(X)
 #undef X
   return n;
+}
+
+int tetris_hip_n_planes(const TetrisDesc* desc) {
+  const int rc = check_desc(desc);
+  if (rc) return rc;
+  return tet::n_planes(desc->num_columns, tet::board_packed(desc->word_bytes, desc->num_rows));
 }
 
 int64_t tetris_hip_status_words(int64_t B) {
@@ -850,6 +864,7 @@ int tetris_hip_reset(const TetrisDesc* desc, void* cols, uint64_t* meta, const u
   p.env_offset = env_offset;
   p.init_bag = init_bag;
   p.n_pieces = desc->n_pieces;
+  p.R = desc->num_rows;
   p.key = tet::hash_key(seed, step_idx * 4u + 2u);
   build_table(desc, &p.tab);
   return dispatch<LaunchReset>(desc, p, (hipStream_t)hip_stream);
@@ -903,8 +918,9 @@ static int fill_step_params(StepParams& p, const TetrisDesc* desc, void* cols, u
   if (B <= 0 || max_elems > 0x7FFFFFFF / 32) return TETRIS_E_BATCH;  // every byte offset (<= 32 B/element) fits 32 bits
   if (stream && (!cursor || stream_len <= 0)) return TETRIS_E_STREAM;
   p.cols = cols;
+  const int n_planes = tet::n_planes(desc->num_columns, tet::board_packed(desc->word_bytes, desc->num_rows));
   for (int c = 0; c < tet::kMaxCols; ++c)
-    p.plane[c] = static_cast<char*>(cols) + (size_t)(c < desc->num_columns ? c : 0) * (size_t)B * desc->word_bytes;
+    p.plane[c] = static_cast<char*>(cols) + (size_t)(c < n_planes ? c : 0) * (size_t)B * desc->word_bytes;
   p.meta = meta;
   p.action = action;
   p.action_out = action_out;
@@ -1039,12 +1055,13 @@ int tetris_hip_decode(const TetrisDesc* desc, const void* cols, int8_t* cells, i
   if (!cols) return TETRIS_E_NULL;
   if (B <= 0) return TETRIS_E_BATCH;
   const int C = desc->num_columns, rows = desc->num_rows + 4;
+  const bool packed = tet::board_packed(desc->word_bytes, desc->num_rows);
   if (desc->word_bytes == 4)
     hipLaunchKernelGGL((decode_kernel<uint32_t>), grid_for(B), dim3(kBlock), 0, (hipStream_t)hip_stream,
-                       static_cast<const uint32_t*>(cols), cells, heights, C, rows, B);
+                       static_cast<const uint32_t*>(cols), cells, heights, C, rows, B, packed);
   else
     hipLaunchKernelGGL((decode_kernel<uint64_t>), grid_for(B), dim3(kBlock), 0, (hipStream_t)hip_stream,
-                       static_cast<const uint64_t*>(cols), cells, heights, C, rows, B);
+                       static_cast<const uint64_t*>(cols), cells, heights, C, rows, B, packed);
   return (int)hipGetLastError();
 }
 
@@ -1054,12 +1071,13 @@ int tetris_hip_encode(const TetrisDesc* desc, const int8_t* cells, void* cols, i
   if (!cols || !cells) return TETRIS_E_NULL;
   if (B <= 0) return TETRIS_E_BATCH;
   const int C = desc->num_columns, rows = desc->num_rows + 4;
+  const bool packed = tet::board_packed(desc->word_bytes, desc->num_rows);
   if (desc->word_bytes == 4)
     hipLaunchKernelGGL((encode_kernel<uint32_t>), grid_for(B), dim3(kBlock), 0, (hipStream_t)hip_stream, cells,
-                       static_cast<uint32_t*>(cols), C, rows, B);
+                       static_cast<uint32_t*>(cols), C, rows, B, packed);
   else
     hipLaunchKernelGGL((encode_kernel<uint64_t>), grid_for(B), dim3(kBlock), 0, (hipStream_t)hip_stream, cells,
-                       static_cast<uint64_t*>(cols), C, rows, B);
+                       static_cast<uint64_t*>(cols), C, rows, B, packed);
   return (int)hipGetLastError();
 }
 

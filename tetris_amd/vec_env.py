@@ -85,7 +85,12 @@ class VecTetris:
 
         B, dev = self.batch_size, self.device
         with torch.device(dev):
-            self.cols = torch.zeros((self.num_columns, B), dtype=self.word_dtype)  # plane-major bitboards
+            # plane-major column bitboards, opaque: one plane per column, or bit-packed four columns to
+            # three words when the stored rows fit three quarters of the word (tetris_hip_n_planes)
+            self.n_planes = int(self._lib.n_planes(ctypes.byref(self.desc)))
+            if self.n_planes <= 0:
+                self._lib.check(self.n_planes, "tetris_hip_n_planes")
+            self.cols = torch.zeros((self.n_planes, B), dtype=self.word_dtype)
             self.meta = torch.zeros(B, dtype=torch.int64)
             self.obs = torch.zeros((B, 8), dtype=torch.float32)
             self.reward = torch.zeros(B, dtype=torch.int32)
@@ -317,6 +322,38 @@ class VecTetris:
             self.meta.copy_((self.meta & keep) | (p << 48))
             self.piece.copy_(p.to(torch.uint8))
         self.refresh()
+
+    def columns(self):
+        """The boards as one bitboard per column, int64 [C, B] (bit r = cell (row r, column c)):
+        the unpacked view of ``cols`` (debugging / tests; the kernels work on ``cols``)."""
+        C, W = self.num_columns, 8 * self.desc.word_bytes
+        planes = self.cols.to(torch.int64)
+        if W == 32:
+            planes = planes & 0xFFFFFFFF
+        if self.n_planes == C:
+            return planes
+        F = W * 3 // 4
+        full = (1 << W) - 1 if W < 64 else -1
+        mask = (1 << F) - 1
+        out = []
+
+        def shr(x, n):  # logical shift right of a W-bit word held in int64
+            if W == 64:
+                return (x >> n) & ((1 << (64 - n)) - 1) if n else x
+            return x >> n
+
+        for c in range(C):
+            b, k = 3 * (c // 4), c % 4
+            if k == 0:
+                v = planes[b]
+            elif k == 1:
+                v = shr(planes[b], F) | (planes[b + 1] << (W - F))
+            elif k == 2:
+                v = shr(planes[b + 1], 2 * F - W) | (planes[b + 2] << (2 * W - 2 * F))
+            else:
+                v = shr(planes[b + 2], 3 * F - 2 * W)
+            out.append(v & mask)
+        return torch.stack(out)
 
     def refresh(self):
         """Recompute valid masks / n_valid from (cols, piece) after a manual edit."""

@@ -10,18 +10,15 @@ sys.path.insert(0, ROOT)
 from tetris_amd import VecTetris, _lib  # noqa: E402
 
 # SWEEP_LIB=<path of a variant built by tools/ablate.py>: time that library's kernels instead
-variant = None
-if os.environ.get("SWEEP_LIB"):
+if os.environ.get("SWEEP_LIB"):  # the whole run (allocation included) goes through the variant library
     import ctypes
-    variant = _lib._Binding(ctypes.CDLL(os.environ["SWEEP_LIB"]))
+    _lib._install_test_backend(_lib._Binding(ctypes.CDLL(os.environ["SWEEP_LIB"])))
 
 for B in [int(x) for x in (sys.argv[1:] or ["65536", "163840", "327680", "655360", "1048576", "1310720", "2097152",
                                             "4194304"])]:
     env = VecTetris(10, 20, B, device="cuda", auto_reset=True, seed=0)
     for t in range(120):
         env.step()
-    if variant is not None:
-        env._lib = variant
     best = 1e9
     for rep in range(3):
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
