@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Turn the two rocprofv3 --pmc passes of tools/pmc_probe.py into per-launch HBM
 bytes of the step kernel, calibrated on refresh_kernel whose traffic is known
-(reads 10 column planes + 8 B meta, writes 8 B meta + 1 B n_valid per env).
+(reads the board planes -- 8 words per env when packed, else 10 -- + 8 B meta, writes 8 B meta + 1 B n_valid per env).
 
 Per MI355X_MICROARCH.md (HBM section): FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950
 FETCH_SIZE under-reports wide streaming reads and other widths are uncalibrated,
@@ -36,7 +36,9 @@ def main():
            "unit_note": "FETCH_SIZE/WRITE_SIZE reported in KiB by rocprofv3"}
     f = load(fetch_dir, "FETCH_SIZE")
     w = load(write_dir, "WRITE_SIZE")
-    known_read = B * (10 * word + 8)
+    rows = int(os.environ.get("PROBE_ROWS", "20"))
+    planes = 8 if rows + 4 <= 6 * word else 10  # packed board storage (tetris_hip_n_planes) for 10 columns
+    known_read = B * (planes * word + 8)
     known_write = B * (8 + 1)
     for tag, rows, known in (("fetch", f, known_read), ("write", w, known_write)):
         ref = [v for k, v in rows if "refresh_kernel" in k]
