@@ -6,80 +6,117 @@
 One "step" = one pass of the hot path over the whole batch: ONE launch of the
 fused step kernel (uniform random valid action per env drawn in-kernel and written
 out, decode, land, lock, clear, done, reward, BCTS observation, in-kernel
-auto-reset), every output tensor written.  Workload at N = 1: BASELINE config 3 -- 1,048,576 envs, 10x20
-board, default piece set; N > 1 is config 4 (weak scaling, 1,048,576 envs per
-GPU, contiguous env shards, no data-path collective; RCCL only gathers the
-done counters / done bitmask).
+auto-reset), every output tensor written.  Workload at N = 1: BASELINE config 3 --
+1,048,576 envs, 10x20 board, default piece set; N > 1 is config 4 (weak scaling,
+1,048,576 envs per GPU, contiguous env shards, no data-path collective; RCCL only
+gathers the done counters / done bitmask).
 
-Prints ONE JSON line (rank 0).  `roofline` prices the step kernel alone against
-HBM: algorithmic bytes per env-step (2*C*W + 47 = 127 B at 10x20,
-207 B at 10x40) x envs per launch / HIP-event kernel time.  `cpu_baseline` times
-the CPU oracle (a port, oracle/) on this host's cores on a bounded sample.
+Ranks.  One process per GPU.  Under torchrun (WORLD_SIZE set) this process IS a rank.
+Started plainly with --gpus N > 1 it is a PARENT that never touches the GPU: it
+starts N fresh rank processes of this script (RANK / LOCAL_RANK / WORLD_SIZE /
+MASTER_ADDR=127.0.0.1 / MASTER_PORT in their environment), forwards rank 0's JSON
+line and exits non-zero if any rank failed.
+
+Prints ONE JSON line (rank 0).  `roofline` prices the step kernel alone against HBM:
+algorithmic bytes per env-step = the board planes actually stored, read + written
+(2 * n_planes * word: 8 planes at 10x20 / 10x40) + the 47 B of SURVEY 8(d)'s fixed
+part = 111 B at 10x20, 175 B at 10x40 (SURVEY's own 127 / 207 B priced ten unpacked
+column words; that figure is kept as `achieved_survey_bytes`), x envs per launch /
+HIP-event kernel time.  `cpu_baseline` times the CPU oracle (a port, oracle/) on this
+host's cores on a bounded sample, single-thread and all-core.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (guides: 8.0 TB/s; ~6.3 TB/s achievable)
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s measured float4 copy)
+FIXED_BYTES = 47       # SURVEY 8(d): action 4 + piece r/w 2 + bag r/w 2 + obs 32 + reward 4 + done/lines/n_valid 3
+FIXED_BYTES_NO_OBS = 15
 
 
-def algorithmic_bytes_per_env_step(C, word_bytes, with_obs=True):
-    return 2 * C * word_bytes + (47 if with_obs else 15)  # SURVEY section 8(d): 127/207 B, 95/175 B without obs
+def algorithmic_bytes_per_env_step(n_planes, word_bytes, with_obs=True):
+    """Board planes as stored (read + write) + the fixed per-env part of SURVEY section 8(d)."""
+    return 2 * n_planes * word_bytes + (FIXED_BYTES if with_obs else FIXED_BYTES_NO_OBS)
 
 
-def cpu_baseline(C, R, pieces, seconds=12.0):
-    """The oracle (CPU restatement, OpenMP over envs) on a bounded sample."""
-    from oracle import oracle as orc
-    import numpy as np
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except Exception:
-        pass
-    cores = min(cores, int(os.environ.get("TETRIS_BENCH_CPU_THREADS", "16")))  # a 1-GPU box's CPU share
-    B = 2048 * cores
-    env = orc.OracleVecEnv(C, R, B, pieces=pieces, auto_reset=True, seed=0, nthreads=cores)
-    rng = np.random.default_rng(0)
+def survey_bytes_per_env_step(C, word_bytes, with_obs=True):
+    """SURVEY section 8(d) as written (one word per column): 127 B at 10x20, 207 B at 10x40."""
+    return 2 * C * word_bytes + (FIXED_BYTES if with_obs else FIXED_BYTES_NO_OBS)
 
-    def one():
-        a = (rng.random(B) * env.n_valid).astype(np.int32)
-        env.step(a)
 
-    for _ in range(3):
-        one()
-    t0 = time.perf_counter()
-    n = 0
-    while time.perf_counter() - t0 < seconds:
-        one()
-        n += 1
-    dt = time.perf_counter() - t0
-    return dict(value=B * n / dt, unit="env-steps/s", cores=cores, kind="port",
-                sample="%d envs x %d steps (oracle/tetris_oracle.c, OpenMP over envs, auto-reset, random "
-                       "valid actions)" % (B, n))
+def csrc_hash():
+    """Content hash of the kernel sources: a committed PMC profile is only quoted for the code it measured."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "tetris_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".hpp", ".inc", ".h")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def load_traffic(columns, rows, pieces, envs):
-    """HBM bytes per launch from the committed PMC profile (profiles/pmc_traffic.json, produced by
-    tools/pmc_probe.py + tools/parse_pmc.py) when it was taken on this very workload, else None."""
+    """HBM bytes per launch of the step kernel from the PMC passes of tools/profile_round.sh
+    (profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, corrected on
+    refresh_kernel as MI355X_MICROARCH.md's HBM section prescribes) -- only when that profile was taken
+    on THIS workload and THESE kernel sources (`csrc_hash`); a stale profile yields None."""
     p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         d = json.load(open(p))
         if (d.get("columns", 10), d.get("rows", 20), d.get("pieces", "default"), d.get("envs")) == \
-                (columns, rows, pieces, envs):
+                (columns, rows, pieces, envs) and d.get("csrc_hash") == csrc_hash():
             return d.get("step_kernel_hbm_bytes_per_launch")
     except Exception:
         pass
     return None
 
 
-def main():
+def cpu_baseline(C, R, pieces, seconds=12.0):
+    """The oracle (CPU restatement, OpenMP over envs) on a bounded sample: one thread, then all cores."""
+    from oracle import oracle as orc
+    import numpy as np
+    visible = os.cpu_count() or 1
+    try:
+        visible = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    cores = min(visible, int(os.environ.get("TETRIS_BENCH_CPU_THREADS", "16")))  # a 1-GPU box's CPU share is 16
+
+    def timed(nthreads, B, budget):
+        env = orc.OracleVecEnv(C, R, B, pieces=pieces, auto_reset=True, seed=0, nthreads=nthreads)
+        rng = np.random.default_rng(0)
+
+        def one():
+            a = (rng.random(B) * env.n_valid).astype(np.int32)
+            env.step(a)
+
+        for _ in range(3):
+            one()
+        t0 = time.perf_counter()
+        n = 0
+        while time.perf_counter() - t0 < budget:
+            one()
+            n += 1
+        return B * n / (time.perf_counter() - t0), n
+
+    v1, n1 = timed(1, 2048, seconds / 3.0)
+    vn, nn = timed(cores, 2048 * cores, seconds * 2.0 / 3.0)
+    return dict(value=vn, unit="env-steps/s", cores=cores, kind="port", single_thread=v1, host_cores_visible=visible,
+                sample="all-core: %d envs x %d steps on %d threads; single-thread: 2048 envs x %d steps "
+                       "(oracle/tetris_oracle.c, OpenMP over envs, auto-reset, random valid actions)"
+                       % (2048 * cores, nn, cores, n1),
+                python_reference_quoted="~181 env-steps/s on 1 core (BASELINE.md section 2; cannot travel)")
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
@@ -90,7 +127,9 @@ def main():
     ap.add_argument("--pieces", default="default")
     ap.add_argument("--gather-every", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-obs", action="store_true", help="skip the observation output (uses 95 B / 175 B per env-step)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the extra roofline keys (4 Mi-env run, 10x40 run, copy peak)")
+    ap.add_argument("--no-obs", action="store_true", help="skip the observation output (32 B per env-step less)")
     ap.add_argument("--fuse", type=int, default=1,
                     help="env-steps per kernel launch (tetris_hip_step_many: boards stay in registers between the "
                          "fused steps, every step's outputs are still written); 1 = one launch per step (headline)")
@@ -99,15 +138,55 @@ def main():
                          "(as the shards of several GPUs are): the tail of one shard's launch overlaps the ramp of "
                          "the next.  1 = one launch over the whole batch per step (headline)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    args = ap.parse_args()
+    return ap.parse_args(argv)
 
+
+# ---- parent: start N rank processes (never touches the GPU, never imports torch) ----------------
+def launch_ranks(args):
+    n = args.gpus
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        sys.stderr.write("bench.py: rank(s) failed: %s\n" % ", ".join("rank %d rc %d" % b for b in bad))
+        return 1
+    return 0
+
+
+# ---- one rank ------------------------------------------------------------------------------------
+def run_rank(args):
+    import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    backend = os.environ.get("TETRIS_BENCH_BACKEND", "nccl")  # "gloo": rehearse N ranks on fewer GPUs
-    dev_index = local_rank % max(1, torch.cuda.device_count()) if world > 1 else 0
-    dev = torch.device("cuda", dev_index)
-    torch.cuda.set_device(dev)
+    if "WORLD_SIZE" in os.environ and args.gpus != world:
+        raise SystemExit("bench.py: --gpus %d disagrees with WORLD_SIZE=%d" % (args.gpus, world))
+    backend = os.environ.get("TETRIS_BENCH_BACKEND", "nccl")  # "gloo": rehearse N ranks on fewer GPUs / on CPU
+    harness = os.environ.get("TETRIS_BENCH_HARNESS") == "1"   # TEST ONLY: CPU harness build of the lane logic
+    if harness:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import harness_backend
+        from tetris_amd import _lib
+        _lib._install_test_backend(harness_backend.binding())
+        dev = torch.device("cpu")
+    else:
+        dev_index = local_rank % max(1, torch.cuda.device_count()) if world > 1 else 0
+        dev = torch.device("cuda", dev_index)
+        torch.cuda.set_device(dev)
+    on_gpu = dev.type == "cuda"
     if world > 1:
         import torch.distributed as dist
         if backend == "nccl":
@@ -118,31 +197,47 @@ def main():
     from tetris_amd import VecTetris
     from tetris_amd.distributed import DoneGather
 
+    def sync():
+        if on_gpu:
+            torch.cuda.synchronize(dev)
+
+    def cur_stream():
+        return torch.cuda.current_stream(dev) if on_gpu else None
+
     B = args.batch
-    S = max(1, args.streams)
+    S = max(1, args.streams) if on_gpu else 1
     if B % S:
         raise SystemExit("--batch must be a multiple of --streams")
-    streams = [torch.cuda.current_stream(dev)] if S == 1 else [torch.cuda.Stream(dev) for _ in range(S)]
+    streams = [cur_stream()] if S == 1 else [torch.cuda.Stream(dev) for _ in range(S)]
+
+    def on_stream(k):
+        return torch.cuda.stream(streams[k]) if on_gpu else _Null()
+
     envs = []
     for k in range(S):  # shard k = global envs [rank*B + k*B/S, ...): the same pieces as one big batch draws
-        with torch.cuda.stream(streams[k]):
+        with on_stream(k):
             envs.append(VecTetris(args.columns, args.rows, B // S, device=dev, pieces=args.pieces, auto_reset=True,
                                   seed=0, env_offset=rank * B + k * (B // S), compute_obs=not args.no_obs))
     env = envs[0]
     gather = DoneGather(B)
 
     def barrier():
-        torch.cuda.synchronize(dev)
+        sync()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize(dev)
+        sync()
 
     def all_totals():
-        for st in streams[1:] if S > 1 else []:
-            torch.cuda.current_stream(dev).wait_stream(st)
         if S > 1:
-            torch.cuda.current_stream(dev).wait_stream(streams[0])
+            for st in streams:
+                cur_stream().wait_stream(st)
         return sum(e.totals() for e in envs)
+
+    def all_done():
+        if S > 1:
+            for st in streams:
+                cur_stream().wait_stream(st)
+        return env.done if S == 1 else torch.cat([e.done for e in envs])
 
     fuse = max(1, args.fuse)
     if args.steps % fuse or args.warmup % fuse:
@@ -155,26 +250,28 @@ def main():
         else:  # `fuse` steps per launch, trajectory buffers reused
             traj[k] = envs[k].step_many(fuse, out=traj[k])
 
+    n_gathers = [0]
+
     def one_step(t):
         if S == 1:
             shard_step(0)
         else:
             for k in range(S):
-                with torch.cuda.stream(streams[k]):
+                with on_stream(k):
                     shard_step(k)
-        if world > 1 and (t + 1) % max(1, args.gather_every // fuse) == 0:
+        if world > 1 and t >= 0 and (t + 1) % max(1, args.gather_every // fuse) == 0:
             gather.gather_counters(all_totals())
+            n_gathers[0] += 1
 
     for t in range(args.warmup // fuse):
         one_step(t)
+    n_gathers[0] = 0
     barrier()
     t0 = time.perf_counter()
     for t in range(args.steps // fuse):
         one_step(t)
     if world > 1:
-        for st in streams:
-            torch.cuda.current_stream(dev).wait_stream(st)
-        gather.gather_bits(env.done if S == 1 else torch.cat([e.done for e in envs]))  # the done/reset gather over RCCL
+        gather.gather_bits(all_done())  # the done/reset gather over RCCL
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -183,29 +280,103 @@ def main():
         dt = float(tt.item())
     totals = gather.gather_counters(all_totals()).cpu().tolist()
 
-    # step-kernel time alone: HIP events on the launch stream (torch's current stream) around
-    # runs of 200 back-to-back launches; per-launch time = elapsed / launches (includes the ~1.5 us
-    # inter-kernel gap, so it reads a few % above rocprofv3's kernel-only average)
-    # (with --streams S > 1 the bracket sits on shard 0's stream: it reads the period at which that
-    # stream's launches complete while the other shards' launches run beside them)
-    n_rep, n_per = 5, 200  # (long runs: the idle-queue start-up of a bracket is amortised over 200 launches)
-    k_ms = []
-    for _ in range(n_rep):
-        s_ev, e_ev = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        s_ev.record(streams[0])
-        for _ in range(n_per):
-            one_step(-2)
-        e_ev.record(streams[0])
-        torch.cuda.synchronize(dev)
-        k_ms.append(s_ev.elapsed_time(e_ev) / n_per)
-    k_ms = sorted(k_ms)[len(k_ms) // 2]
+    # step-kernel time alone: HIP events on the launch stream (torch's current stream) around runs
+    # of back-to-back launches; per-launch time = elapsed / launches (includes the ~1.5 us
+    # inter-kernel gap, so it reads a few % above rocprofv3's kernel-only average).  With
+    # --streams S > 1 the bracket sits on shard 0's stream: it reads the period at which that
+    # stream's launches complete while the other shards' launches run beside them.
+    def kernel_ms_of(step_fn, stream, n_rep=5, n_per=200):
+        if not on_gpu:
+            t = time.perf_counter()
+            for _ in range(4):
+                step_fn()
+            return (time.perf_counter() - t) / 4 * 1e3
+        ms = []
+        for _ in range(n_rep):
+            s_ev, e_ev = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s_ev.record(stream)
+            for _ in range(n_per):
+                step_fn()
+            e_ev.record(stream)
+            torch.cuda.synchronize(dev)
+            ms.append(s_ev.elapsed_time(e_ev) / n_per)
+        return sorted(ms)[len(ms) // 2]
+
+    k_ms = kernel_ms_of(lambda: one_step(-2), streams[0])
     for e in envs:
         e.check()
 
+    # the done/reset gather on its own (it sits outside the kernel bracket above): bitmask
+    # all-gather + counter all-reduce, host-paired wall time per call
+    gather_ms = None
+    k_all = [k_ms]
+    if world > 1:
+        barrier()
+        g0 = time.perf_counter()
+        for _ in range(10):
+            gather.gather_bits(all_done())
+            gather.gather_counters(all_totals())
+        sync()
+        gather_ms = (time.perf_counter() - g0) / 10 * 1e3
+        kt = torch.tensor([k_ms], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        parts = [torch.zeros_like(kt) for _ in range(world)]
+        dist.all_gather(parts, kt)
+        k_all = [float(x.item()) for x in parts]
+
+    extras = {}
+    if rank == 0 and world == 1 and on_gpu and not args.no_extras and fuse == 1 and S == 1 and not args.no_obs:
+        # (a) the same kernel with a working set beyond the 256 MiB Infinity Cache (4 Mi envs, ~0.5 GB per step)
+        big = VecTetris(args.columns, args.rows, 4 * B, device=dev, pieces=args.pieces, auto_reset=True, seed=0)
+        for _ in range(args.warmup):
+            big.step()
+        extras["kernel_ms_4Mi"] = kernel_ms_of(big.step, cur_stream(), n_rep=3, n_per=50)
+        del big
+        # (b) config 5 shape: 10x40 boards (u64 columns), same batch
+        tall = VecTetris(args.columns, 40, B, device=dev, pieces=args.pieces, auto_reset=True, seed=0)
+        for _ in range(args.warmup):
+            tall.step()
+        tall_ms = kernel_ms_of(tall.step, cur_stream(), n_rep=3, n_per=100)
+        tall_alg = algorithmic_bytes_per_env_step(tall.n_planes, tall.desc.word_bytes)
+        extras["tall_10x40"] = {"kernel_ms": tall_ms, "env_steps_per_s": B / (tall_ms * 1e-3), "dtype": "u64",
+                                "algorithmic_bytes_per_env_step": tall_alg,
+                                "frac": tall_alg * B / (tall_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        del tall
+        # (c) what this box's HBM delivers to a plain copy (1 GiB read + 1 GiB written per pass)
+        src = torch.empty(1 << 28, dtype=torch.float32, device=dev)
+        dst = torch.empty_like(src)
+        src.fill_(1.0)
+        cp_ms = kernel_ms_of(lambda: dst.copy_(src), cur_stream(), n_rep=3, n_per=10)
+        extras["peak_copy_measured"] = 2.0 * src.numel() * 4 / (cp_ms * 1e-3) / 1e9
+        del src, dst
+        torch.cuda.empty_cache()
+
     if rank == 0:
-        alg = algorithmic_bytes_per_env_step(args.columns, env.desc.word_bytes, not args.no_obs)
+        wb = env.desc.word_bytes
+        alg = algorithmic_bytes_per_env_step(env.n_planes, wb, not args.no_obs)
+        alg_survey = survey_bytes_per_env_step(args.columns, wb, not args.no_obs)
         # S shard launches of B/S envs run beside each other during every period k_ms
         achieved = alg * B * fuse / (k_ms * 1e-3) / 1e9
+        traffic = None if (args.no_obs or fuse > 1 or S > 1) else load_traffic(args.columns, args.rows, args.pieces, B)
+        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "kernel": "step_kernel" if fuse == 1 else "step_many_kernel (%d steps per launch)" % fuse,
+                "kernel_ms": k_ms, "algorithmic_bytes_per_env_step": alg,
+                "survey_bytes_per_env_step": alg_survey,
+                "achieved_survey_bytes": alg_survey * B * fuse / (k_ms * 1e-3) / 1e9,
+                "peak_spec": HBM_PEAK_GBS,
+                "note": "working set of one launch (~%d MB) fits the 256 MiB Infinity Cache, whose hits FETCH_SIZE / "
+                        "WRITE_SIZE count: see frac_4Mi for the same kernel streaming from HBM" % (alg * B // 1000000)}
+        if traffic is not None:
+            roof["achieved_measured"] = traffic / (k_ms * 1e-3) / 1e9
+            roof["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc, csrc_hash %s)" % csrc_hash()
+        if world > 1:
+            roof["kernel_ms_per_rank"] = {"min": min(k_all), "max": max(k_all)}
+        if "kernel_ms_4Mi" in extras:
+            roof["kernel_ms_4Mi"] = extras["kernel_ms_4Mi"]
+            roof["frac_4Mi"] = alg * 4 * B / (extras["kernel_ms_4Mi"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+        if "peak_copy_measured" in extras:
+            roof["peak_copy_measured"] = extras["peak_copy_measured"]
+            roof["frac_of_copy_peak"] = achieved / extras["peak_copy_measured"]
         out = {
             "metric": "env-steps/sec",
             "value": B * world * args.steps / dt,
@@ -217,27 +388,48 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "u32" if env.desc.word_bytes == 4 else "u64",
+            "dtype": "u32" if wb == 4 else "u64",
             "data": "synthetic",
             "config": {"workload": "%d envs/GPU x %d GPU, %dx%d board, pieces=%s, uniform random valid actions, "
                                    "in-kernel auto-reset, device bag seed 0" % (B, world, args.columns, args.rows,
                                                                                 args.pieces),
                        "envs_per_gpu": B, "observation_output": not args.no_obs, "env_steps_per_launch": fuse,
                        "streams_per_gpu": S, "board": "%dx%d" % (args.columns, args.rows), "pieces": args.pieces,
+                       "backend": ("harness-cpu/" if harness else "") + (backend if world > 1 else "single"),
                        "sharding": "env-index ranges, no data-path collective; RCCL gathers done counters every "
                                    "%d steps + done bitmask at the end" % args.gather_every},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None if (args.no_obs or fuse > 1 or S > 1) else load_traffic(args.columns, args.rows, args.pieces, B),
-                         "kernel": "step_kernel" if fuse == 1 else "step_many_kernel (%d steps per launch)" % fuse, "kernel_ms": k_ms, "algorithmic_bytes_per_env_step": alg},
+            "roofline": roof,
             "episodes": totals[1], "lines_cleared": totals[2],
         }
+        if world > 1:
+            out["done_gather"] = {"ms_per_gather": gather_ms, "counter_gathers_in_timed_region": n_gathers[0],
+                                  "bitmask_gathers_in_timed_region": 1}
+        if "tall_10x40" in extras:
+            out["tall_10x40"] = extras["tall_10x40"]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.columns, args.rows, args.pieces, args.cpu_seconds)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    return 0
+
+
+class _Null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+def main():
+    args = parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return launch_ranks(args)
+    return run_rank(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -49,6 +49,10 @@ def main():
                     "step_raw_bytes": raw_step, "step_corrected_bytes": raw_step * known / raw_ref}
     out["step_kernel_hbm_bytes_per_launch"] = out["fetch"]["step_corrected_bytes"] + out["write"]["step_corrected_bytes"]
     out["step_kernel_hbm_bytes_per_env_step"] = out["step_kernel_hbm_bytes_per_launch"] / B
+    # key the profile to the kernel sources it measured: bench.py quotes it only while they are unchanged
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    out["csrc_hash"] = bench.csrc_hash()
     print(json.dumps(out, indent=1))
 
 

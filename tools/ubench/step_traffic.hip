@@ -1,0 +1,211 @@
+// Memory-side microbenchmark of the step kernel: the SAME loads and stores per env-step as
+// tetris_hip_step (10x20 board, packed planes, all outputs) with next to no arithmetic, in several
+// layouts, to find out what the memory floor of one launch over B envs is and which layout
+// choices move it.  Every variant reads its state, changes it a little (so nothing is elided and
+// written lines differ from read ones) and writes every output.
+//
+//   V0  current layout: 8 u32 planes [p][B] + u64 meta [B]; outputs obs 2 x float4 per lane,
+//       reward i32, action i32, four u8 arrays, one uint4 status slot per wave (read + write)
+//   V1  V0 with the four u8 outputs merged into one u32 "flags" word per env
+//   V2  V1 with meta folded into the state: 9 u32 planes, no u64 meta
+//   V3  V2 with the state tile-major: [B/64][9][64] words (one contiguous 2,304 B record per wave)
+//   V4  V3 + obs written transposed (each store instruction covers 1 KiB contiguous)
+//   V5  V0 + the per-workgroup table staging of the real kernel (7 KiB + 2.4 KiB from L2 into LDS)
+//   V6  plain float4 copy of the same number of bytes (upper bound of this chip for the byte count)
+// BLK = 256 or 512 threads per workgroup.
+// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 step_traffic.hip -o step_traffic
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <cstdint>
+
+struct Ptrs {
+  uint32_t* planes;   // 9 * B words (V0/V1 use 8)
+  uint64_t* meta;
+  float4* obs;        // 2 * B
+  int32_t* reward;
+  int32_t* action;
+  uint8_t* done;
+  uint8_t* lines;
+  uint8_t* nvalid;
+  uint8_t* piece;
+  uint32_t* flags;
+  uint4* status;
+  const uint4* lut;   // 9.4 KiB of table bytes
+  uint32_t B;
+};
+
+template <int V, int BLK>
+__global__ __launch_bounds__(BLK) void traffic(const Ptrs p) {
+  constexpr int NP = (V >= 2 && V <= 4) ? 9 : 8;
+  const uint32_t i = blockIdx.x * BLK + threadIdx.x;
+  if (i >= p.B) return;
+  __shared__ uint4 lds[(V == 5) ? 602 : 1];
+  uint32_t w[NP];
+  const uint32_t wave = i >> 6, lane = i & 63;
+#pragma unroll
+  for (int q = 0; q < NP; ++q) {
+    if (V == 3 || V == 4)
+      w[q] = p.planes[(size_t)wave * (NP * 64) + q * 64 + lane];
+    else
+      w[q] = p.planes[(size_t)q * p.B + i];
+  }
+  uint64_t meta = 0;
+  if (V < 2 || V >= 5) meta = p.meta[i];
+  uint4 st = p.status[wave];
+  uint32_t extra = 0;
+  if (V == 5) {
+    for (int t = threadIdx.x; t < 602; t += BLK) lds[t] = p.lut[t];
+    __syncthreads();
+    extra = lds[(w[0] ^ threadIdx.x) % 602].x;
+  }
+  uint32_t acc = (uint32_t)meta ^ (uint32_t)(meta >> 32) ^ extra;
+#pragma unroll
+  for (int q = 0; q < NP; ++q) {
+    acc = acc * 0x9E3779B1u + w[q];
+    w[q] = w[q] * 5u + 1u;
+  }
+#pragma unroll
+  for (int q = 0; q < NP; ++q) {
+    if (V == 3 || V == 4)
+      p.planes[(size_t)wave * (NP * 64) + q * 64 + lane] = w[q];
+    else
+      p.planes[(size_t)q * p.B + i] = w[q];
+  }
+  if (V < 2 || V >= 5) p.meta[i] = meta + acc;
+  float f[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) f[q] = (float)((acc >> (3 * q)) & 31u);
+  if (V == 4) {
+    // transposed: instruction A covers rows 0..31 of the wave (lane L writes half L%2 of row L/2),
+    // instruction B rows 32..63; values travel through ds_bpermute
+    float4 a, b;
+    {
+      const int srcA = (int)(lane >> 1), srcB = 32 + (int)(lane >> 1);
+      const bool hi = lane & 1;
+      float ga[4], gb[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float lo_a = __shfl(f[q], srcA), hi_a = __shfl(f[q + 4], srcA);
+        const float lo_b = __shfl(f[q], srcB), hi_b = __shfl(f[q + 4], srcB);
+        ga[q] = hi ? hi_a : lo_a;
+        gb[q] = hi ? hi_b : lo_b;
+      }
+      a = make_float4(ga[0], ga[1], ga[2], ga[3]);
+      b = make_float4(gb[0], gb[1], gb[2], gb[3]);
+    }
+    float4* o = p.obs + (size_t)wave * 128;
+    o[lane] = a;
+    o[64 + lane] = b;
+  } else {
+    p.obs[2 * (size_t)i] = make_float4(f[0], f[1], f[2], f[3]);
+    p.obs[2 * (size_t)i + 1] = make_float4(f[4], f[5], f[6], f[7]);
+  }
+  p.reward[i] = (int32_t)(acc & 3u) - 1;
+  p.action[i] = (int32_t)(acc >> 27);
+  if (V == 0 || V == 5) {
+    p.done[i] = (uint8_t)(acc & 1u);
+    p.lines[i] = (uint8_t)((acc >> 1) & 3u);
+    p.nvalid[i] = (uint8_t)((acc >> 3) & 31u);
+    p.piece[i] = (uint8_t)((acc >> 8) & 1u);
+  } else {
+    p.flags[i] = acc & 0x01031F01u;
+  }
+  const unsigned long long m = __ballot(acc & 1u);
+  if (lane == 0) {
+    st.y += (unsigned)__popcll(m);
+    st.w += 64;
+    p.status[wave] = st;
+  }
+}
+
+__global__ __launch_bounds__(256) void copy4(const float4* __restrict__ src, float4* __restrict__ dst, size_t n) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dst[i] = src[i];
+}
+
+template <int V, int BLK>
+float run(const Ptrs& p, int reps) {
+  hipEvent_t s, e;
+  hipEventCreate(&s);
+  hipEventCreate(&e);
+  const int grid = (p.B + BLK - 1) / BLK;
+  for (int i = 0; i < 20; ++i) hipLaunchKernelGGL((traffic<V, BLK>), dim3(grid), dim3(BLK), 0, 0, p);
+  float best = 1e9f;
+  for (int r = 0; r < 3; ++r) {
+    hipEventRecord(s, 0);
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((traffic<V, BLK>), dim3(grid), dim3(BLK), 0, 0, p);
+    hipEventRecord(e, 0);
+    hipEventSynchronize(e);
+    float ms = 0;
+    hipEventElapsedTime(&ms, s, e);
+    if (ms / reps < best) best = ms / reps;
+  }
+  return best * 1e3f;
+}
+
+static double bytes_of(int V) {
+  // per env: state r/w + outputs
+  const double out_common = 32 + 4 + 4 + 4 + 0.5;  // obs, reward, action, 4 flag bytes, status r/w
+  if (V >= 2 && V <= 4) return 2 * 36 + out_common;
+  return 2 * 32 + 2 * 8 + out_common;
+}
+
+int main(int argc, char** argv) {
+  for (int pass = 0; pass < 2; ++pass) {
+    const uint32_t B = pass == 0 ? (1u << 20) : (1u << 22);
+    Ptrs p;
+    memset(&p, 0, sizeof(p));
+    p.B = B;
+#define ALLOC(field, bytes)                                               \
+  if (hipMalloc((void**)&p.field, (bytes)) != hipSuccess) return 1;       \
+  hipMemset(p.field, 1, (bytes));
+    ALLOC(planes, (size_t)9 * B * 4)
+    ALLOC(meta, (size_t)B * 8)
+    ALLOC(obs, (size_t)B * 32)
+    ALLOC(reward, (size_t)B * 4)
+    ALLOC(action, (size_t)B * 4)
+    ALLOC(done, (size_t)B)
+    ALLOC(lines, (size_t)B)
+    ALLOC(nvalid, (size_t)B)
+    ALLOC(piece, (size_t)B)
+    ALLOC(flags, (size_t)B * 4)
+    ALLOC(status, (size_t)(B / 64) * 16)
+    uint4* lut;
+    if (hipMalloc((void**)&lut, 602 * 16) != hipSuccess) return 1;
+    hipMemset(lut, 3, 602 * 16);
+    p.lut = lut;
+    const int reps = pass == 0 ? 200 : 60;
+    printf("---- B = %u envs ----\n", B);
+#define RUN(V, BLK)                                                                                        \
+  {                                                                                                        \
+    const float us = run<V, BLK>(p, reps);                                                                 \
+    printf("V%d blk %3d: %7.2f us  %6.1f B/env  %.2f TB/s\n", V, BLK, us, bytes_of(V), bytes_of(V) * B / us / 1e6); \
+  }
+    RUN(0, 256) RUN(0, 512) RUN(1, 256) RUN(1, 512) RUN(2, 256) RUN(2, 512) RUN(3, 256) RUN(3, 512) RUN(4, 256)
+    RUN(4, 512) RUN(5, 256) RUN(5, 512)
+    {
+      const size_t n = (size_t)(bytes_of(0) * B / 2 / 16);  // read n float4 + write n float4 = the bytes of V0
+      float4 *a, *b;
+      if (hipMalloc((void**)&a, n * 16) != hipSuccess || hipMalloc((void**)&b, n * 16) != hipSuccess) return 1;
+      hipMemset(a, 1, n * 16);
+      hipEvent_t s, e;
+      hipEventCreate(&s);
+      hipEventCreate(&e);
+      for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(copy4, dim3((n + 255) / 256), dim3(256), 0, 0, a, b, n);
+      hipEventRecord(s, 0);
+      for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(copy4, dim3((n + 255) / 256), dim3(256), 0, 0, a, b, n);
+      hipEventRecord(e, 0);
+      hipEventSynchronize(e);
+      float ms = 0;
+      hipEventElapsedTime(&ms, s, e);
+      printf("V6 float4 copy of the same bytes: %7.2f us  %.2f TB/s\n", ms / reps * 1e3, 2.0 * n * 16 / (ms / reps) / 1e9);
+      hipFree(a);
+      hipFree(b);
+    }
+    hipFree(p.planes); hipFree(p.meta); hipFree(p.obs); hipFree(p.reward); hipFree(p.action); hipFree(p.done);
+    hipFree(p.lines); hipFree(p.nvalid); hipFree(p.piece); hipFree(p.flags); hipFree(p.status); hipFree(lut);
+  }
+  return 0;
+}
