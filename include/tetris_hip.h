@@ -144,6 +144,11 @@ int tetris_hip_reset(const TetrisDesc* desc, void* cols, uint64_t* meta, const u
  * An out-of-range action (game.py:83 raises IndexError) leaves that env
  * untouched, writes obs = 0, reward = 0, lines = 0 and counts it in
  * status[TETRIS_STATUS_INVALID].
+ * Replay mode: a step consumes one stream row, two when it ends the episode under
+ * auto_reset.  An env whose cursor cannot cover that (cursor + 1, or + 2 with auto_reset,
+ * > stream_len) is treated exactly like an out-of-range action: untouched and counted as
+ * invalid -- the recorded game is never continued with made-up pieces.  (tetris_hip_reset
+ * past the end of the stream re-reads the last row; the next step then reports the env.)
  */
 int tetris_hip_step(const TetrisDesc* desc, void* cols, uint64_t* meta, const int32_t* action,
                     int32_t* action_out, const uint8_t* stream, int32_t* cursor, int64_t stream_len, float* obs,

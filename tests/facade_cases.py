@@ -128,3 +128,87 @@ def rollouts_and_misc(device):
     except ValueError:
         pass
     assert "|" in repr(env.current_state) and "██" in repr(env.tetrominos[0])
+
+
+def _policy_holes_height(state, feats):
+    return int(np.argmin(feats[:, 2] + feats[:, 3]))
+
+
+def _bag_row(env):
+    return np.pad(np.asarray(env.tetromino_sampler.current_batch, np.int64) + 1, (0, 12))[:12]
+
+
+def _rng_fingerprint():
+    import zlib
+    st = np.random.get_state()
+    return np.array([st[2], zlib.crc32(st[1].tobytes())], np.int64)
+
+
+def rollout_script(device, golden_dir):
+    """g7 part A: the seeded script of single_rollout / perform_rollouts calls recorded from the reference
+    (game.py:129-160): every return, the bag and NumPy's global stream after every block, and the
+    restored state must match.  perform_rollouts with length > 1 is compared with the reference's loop
+    run on a refreshed afterstate list (see make_golden.gen_rollouts for the stale-list quirk)."""
+    from tetris_amd import Tetris
+    g = np.load(os.path.join(golden_dir, "g7_rollouts.npz"))
+    for tag, pieces, R in (("default_10", "default", 10), ("standard7_12", STANDARD7, 12)):
+        np.random.seed(int(g[tag + "_seed"]))
+        env = Tetris(10, R, pieces=pieces, device=device)
+        k = 0
+        deaths = 0
+        for op in g[tag + "_ops"]:
+            if op >= 0:
+                env.get_after_states()
+                env.step(int(op))
+            elif op == -1:
+                env.reset()
+            else:
+                np.testing.assert_array_equal(_cols_of(env.current_state.representation), g[tag + "_boards"][k])
+                piece = env.tetrominos.index(env.current_tetromino)
+                assert piece == g[tag + "_pieces"][k]
+                rec = g[tag + "_single"][k]
+                length, n_act = int(rec[0]), int(rec[1])
+                fv, _ = env.get_after_states()
+                assert min(fv.shape[0], 6) == n_act
+                for act in range(n_act):
+                    env.get_after_states()
+                    r = env.single_rollout(act, _policy_holes_height, length)
+                    assert r == rec[2 + act], (tag, k, act, r, rec[2 + act])
+                    deaths += int(r == -1 and length > 2)
+                    assert env.tetrominos.index(env.current_tetromino) == piece       # game.py:147-148
+                    np.testing.assert_array_equal(_cols_of(env.current_state.representation), g[tag + "_boards"][k])
+                np.testing.assert_array_equal(_bag_row(env), g[tag + "_bags"][2 * k])  # the bag advanced as upstream
+                np.testing.assert_array_equal(_rng_fingerprint(), g[tag + "_rng"][2 * k])
+                env.get_after_states()
+                acts, rets = env.perform_rollouts(list(range(min(fv.shape[0], 4))), _policy_holes_height, length=1, n=3)
+                np.testing.assert_array_equal(rets, g[tag + "_perform_len1"][k][:len(rets)])
+                assert acts == list(range(min(fv.shape[0], 4)))
+                acts, rets = env.perform_rollouts(list(range(min(fv.shape[0], 3))), _policy_holes_height,
+                                                  length=length, n=2)
+                np.testing.assert_array_equal(rets, g[tag + "_perform_fresh"][k][:len(rets)])
+                np.testing.assert_array_equal(_bag_row(env), g[tag + "_bags"][2 * k + 1])
+                np.testing.assert_array_equal(_rng_fingerprint(), g[tag + "_rng"][2 * k + 1])
+                k += 1
+        assert k == len(g[tag + "_boards"]) and deaths > 0
+
+
+def render_strings(device, golden_dir):
+    """g8: State.__repr__ / print_board_to_string (state.py:69-81: the R legal rows), utils.print_board_to_string
+    (utils.py:179-191: all R + 4 rows) and the piece reprs, character for character."""
+    from tetris_amd import Tetris
+    from tetris_amd.state import State, print_board_to_string
+    g = np.load(os.path.join(golden_dir, "g8_render.npz"))
+    for i in range(int(g["n_states"])):
+        cols = g["s%d_cols" % i]
+        rep = ((cols[None, :] >> np.arange(12, dtype=np.uint64)[:, None]) & np.uint64(1)).astype(np.int_)
+        st = State(rep)
+        assert st.print_board_to_string() == str(g["s%d_state_str" % i])
+        assert repr(st) == str(g["s%d_repr" % i])
+        assert print_board_to_string(st) == str(g["s%d_utils_str" % i])
+    env = Tetris(10, 8, pieces=["Straight", "Square", "SnakeR", "ThreeLine", "ThreeL", "SnakeL", "T", "RCorner",
+                                "LCorner"], device=device)
+    for t in env.tetrominos:
+        if int(g["piece_%s_has_custom_repr" % t.name]):
+            assert repr(t) == str(g["piece_%s_repr" % t.name]), t.name
+        else:
+            assert "██" in repr(t)  # upstream falls back to the default object repr (tetromino.py:162 typo)

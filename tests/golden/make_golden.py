@@ -18,6 +18,11 @@ Fixture families:
   g3_rng            np.random.permutation bags for seeds 0..15
   g4_edges          hand-built edge cases
   g5_dtypes         observation dtypes with / without feature_directions
+  g6_policy         get_best_policy / fitness vectors on trajectory states
+  g7_rollouts       single_rollout / perform_rollouts scripts (returns, bag and
+                    global-RNG state after every call) and one-piece-set rollout
+                    returns that pin the batched rollout kernel
+  g8_render         print_board_to_string / State.__repr__ / piece reprs
 """
 import os
 import sys
@@ -329,8 +334,185 @@ def gen_policy_rollouts(game, tetromino):
     return out
 
 
+BCTS_W = [-24.04, -19.77, -13.08, -12.63, -10.49, -9.22, 6.6, -1.61]  # game.py:111-118
+
+
+def policy_holes_height(state, feats):
+    """Deterministic rollout policy of the facade script: least holes + landing height, first minimum."""
+    return int(np.argmin(feats[:, 2] + feats[:, 3]))
+
+
+def policy_greedy_f32(state, feats):
+    """The batched kernel's greedy policy restated for the reference's policy_function hook: linear
+    fitness in float32, every product and partial sum rounded, first maximum."""
+    f = np.asarray(feats, np.float32)
+    w = np.asarray(BCTS_W, np.float32)
+    acc = f[:, 0] * w[0]
+    for q in range(1, 8):
+        acc = (acc + f[:, q] * w[q]).astype(np.float32)
+    return int(np.argmax(acc))
+
+
+def rng_fingerprint():
+    import zlib
+    st = np.random.get_state()
+    return np.array([st[2], zlib.crc32(st[1].tobytes())], np.int64)
+
+
+def gen_rollouts(game, tetromino):
+    """game.py:129-160.  Part A: a seeded script of single_rollout / perform_rollouts calls on
+    mid-game states (the facade replays it on the same np.random stream).  The reference's
+    perform_rollouts calls step(action) on whatever `self.afterstates` the previous rollout left
+    behind (game.py:134 reads the list of game.py:69, which single_rollout's own policy calls
+    replace), so with length > 1 its later rollouts start from a stale list; the script therefore
+    records (i) perform_rollouts verbatim with length 1, where the list cannot go stale, and (ii) the
+    same double loop with get_after_states() refreshed before every single_rollout (`fresh`), which is
+    what tetris_amd.Tetris.perform_rollouts does.  Part B: one-piece sets (the bag is then
+    deterministic) with the float32 greedy policy, per (state, first action) returns: the batched
+    kernel must reproduce them exactly."""
+    out = {}
+    deaths = [0]
+
+    def watch(env):  # generator-side diagnostics only: how many rollout steps ended a game
+        real = env.step
+
+        def step(a):
+            r = real(a)
+            deaths[0] += int(r[2])
+            return r
+        env.step = step
+        return env
+
+    for tag, names, R, seed in (("default_10", None, 10, 11), ("standard7_12", STANDARD7, 12, 12)):
+        env = watch(make_env(game, tetromino, 10, R, names, seed))
+        arng = np.random.default_rng(500 + seed)
+        ops, boards, pieces, singles, bags, rngs, perf1, perff = [], [], [], [], [], [], [], []
+        n_states = 0
+        while n_states < 20:
+            fv, _ = env.get_after_states()
+            a = int(arng.integers(fv.shape[0]))
+            _, _, done, _ = env.step(a)
+            ops.append(a)
+            if done:
+                env.reset()
+                ops.append(-1)
+                continue
+            tall = int(np.max(env.current_state.lowest_free_rows)) >= R - 3
+            if arng.random() < (0.2 if tall else 0.8):  # mostly near-top states: rollouts must also die
+                continue
+            # a rollout state
+            ops.append(-2)
+            n_states += 1
+            boards.append(cols_of(env.current_state.representation))
+            pieces.append(env.tetrominos.index(env.current_tetromino))
+            fv, _ = env.get_after_states()
+            nv = fv.shape[0]
+            length = int(arng.integers(2, 6))
+            row = np.full(40, 99, np.int32)
+            for act in range(min(nv, 6)):
+                env.get_after_states()
+                row[act] = env.single_rollout(act, policy_holes_height, length)
+                assert env.tetrominos.index(env.current_tetromino) == pieces[-1]
+            singles.append(np.concatenate([[length, min(nv, 6)], row]))
+            bags.append(np.pad(np.asarray(env.tetromino_sampler.current_batch, np.int64) + 1, (0, 12))[:12])
+            rngs.append(rng_fingerprint())
+            # (i) the reference's own double loop, length 1
+            env.get_after_states()
+            acts, rets = env.perform_rollouts(list(range(min(nv, 4))), policy_holes_height, length=1, n=3)
+            r1 = np.full(8, 99.0)
+            r1[:len(rets)] = rets
+            perf1.append(r1)
+            # (ii) refreshed list before every rollout
+            rf = np.full(8, 99.0)
+            for act in range(min(nv, 3)):
+                rr = []
+                for _ in range(2):
+                    env.get_after_states()
+                    rr.append(env.single_rollout(act, policy_holes_height, length))
+                rf[act] = np.mean(rr)
+            perff.append(rf)
+            bags.append(np.pad(np.asarray(env.tetromino_sampler.current_batch, np.int64) + 1, (0, 12))[:12])
+            rngs.append(rng_fingerprint())
+        out[tag + "_seed"] = np.int64(seed)
+        out[tag + "_ops"] = np.array(ops, np.int16)
+        out[tag + "_boards"] = np.array(boards, np.uint64)
+        out[tag + "_pieces"] = np.array(pieces, np.int8)
+        out[tag + "_single"] = np.array(singles, np.int32)
+        out[tag + "_bags"] = np.array(bags, np.int8)      # two rows per state: after the singles, after the performs
+        out[tag + "_rng"] = np.array(rngs, np.int64)
+        out[tag + "_perform_len1"] = np.array(perf1)
+        out[tag + "_perform_fresh"] = np.array(perff)
+    # Part B
+    out["weights"] = np.array(BCTS_W, np.float64)
+    for tag, name, R, seed, length in (("one_T_10", "T", 10, 21, 4), ("one_ThreeL_8", "ThreeL", 8, 22, 5),
+                                        ("one_Straight_9", "Straight", 9, 23, 3)):
+        env = watch(make_env(game, tetromino, 10, R, [name], seed))
+        arng = np.random.default_rng(900 + seed)
+        boards, rets = [], []
+        while len(boards) < 24:
+            fv, _ = env.get_after_states()
+            _, _, done, _ = env.step(int(arng.integers(fv.shape[0])))
+            if done:
+                env.reset()
+                continue
+            tall = int(np.max(env.current_state.lowest_free_rows)) >= R - 3
+            if arng.random() < (0.2 if tall else 0.8):
+                continue
+            boards.append(cols_of(env.current_state.representation))
+            fv, _ = env.get_after_states()
+            row = np.full(40, np.nan)
+            for act in range(fv.shape[0]):
+                env.get_after_states()
+                row[act] = env.single_rollout(act, policy_greedy_f32, length)
+            rets.append(row)
+        out[tag + "_boards"] = np.array(boards, np.uint64)
+        out[tag + "_returns"] = np.array(rets)
+        out[tag + "_length"] = np.int64(length)
+        out[tag + "_rows"] = np.int64(R)
+    print("g7: %d game-ending steps seen while generating (rollouts + driver play)" % deaths[0])
+    return out
+
+
+def gen_render(game, state, tetromino, utils):
+    """state.py:69-81 (State.__repr__ / print_board_to_string: the R legal rows) and utils.py:179-191
+    (all R + 4 stored rows) on three states; repr of the pieces that define one."""
+    out = {}
+    np.random.seed(31)
+    env = game.Tetris(10, 8)
+    arng = np.random.default_rng(31)
+    texts = []
+    for t in range(14):
+        fv, _ = env.get_after_states()
+        _, _, done, _ = env.step(int(arng.integers(fv.shape[0])))
+        if done:
+            break
+        if t in (0, 6, 12):
+            st = env.current_state
+            out["s%d_cols" % len(texts)] = cols_of(st.representation)
+            out["s%d_state_str" % len(texts)] = np.array(st.print_board_to_string())
+            out["s%d_repr" % len(texts)] = np.array(repr(st))
+            out["s%d_utils_str" % len(texts)] = np.array(utils.print_board_to_string(st))
+            texts.append(t)
+    out["n_states"] = np.int64(len(texts))
+    for name in CATALOGUE:
+        piece = getattr(tetromino, name)("bcts", 8, 10)
+        r = repr(piece)
+        out["piece_%s_has_custom_repr" % name] = np.int8(not r.startswith("<"))
+        if not r.startswith("<"):
+            out["piece_%s_repr" % name] = np.array(r)
+    return out
+
+
 def main():
     game, state, tetromino = import_reference()
+    only = set(sys.argv[1:])  # e.g. `make_golden.py g7 g8` regenerates just those families
+    if only:
+        if "g7" in only:
+            np.savez_compressed(os.path.join(HERE, "g7_rollouts.npz"), **gen_rollouts(game, tetromino))
+        if "g8" in only:
+            from tetris import utils
+            np.savez_compressed(os.path.join(HERE, "g8_render.npz"), **gen_render(game, state, tetromino, utils))
+        return
     np.savez_compressed(os.path.join(HERE, "g1_placements_10x20.npz"),
                         **gen_placements(game, state, tetromino, 20, 10, 56, seed=1))
     np.savez_compressed(os.path.join(HERE, "g1_placements_10x40.npz"),
@@ -349,6 +531,9 @@ def main():
     np.savez_compressed(os.path.join(HERE, "g4_edges.npz"), **gen_edges(game, state, tetromino))
     np.savez_compressed(os.path.join(HERE, "g5_dtypes.npz"), **gen_dtypes(game))
     np.savez_compressed(os.path.join(HERE, "g6_policy.npz"), **gen_policy_rollouts(game, tetromino))
+    np.savez_compressed(os.path.join(HERE, "g7_rollouts.npz"), **gen_rollouts(game, tetromino))
+    from tetris import utils
+    np.savez_compressed(os.path.join(HERE, "g8_render.npz"), **gen_render(game, state, tetromino, utils))
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

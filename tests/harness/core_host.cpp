@@ -72,8 +72,10 @@ void step_impl(const TetrisDesc* desc, void* cols_, uint64_t* meta, const int32_
     host_load<W, C>(cols, B, i, desc->num_rows, col);
     uint64_t m = meta[i];
     int draw = -1, draw_reset = -1, cur = 0;
+    bool exhausted = false;
     if (stream) {
       cur = cursor[i];
+      exhausted = (int64_t)cur + (auto_reset ? 2 : 1) > stream_len || cur < 0;
       int64_t r0 = cur < stream_len ? cur : stream_len - 1;
       int64_t r1 = cur + 1 < stream_len ? cur + 1 : stream_len - 1;
       draw = stream[r0 * B + i];
@@ -82,13 +84,13 @@ void step_impl(const TetrisDesc* desc, void* cols_, uint64_t* meta, const int32_
     tet::StepOut out;
     W scratch[C];
     if (sizeof(W) == 4 && cfg.R <= 20)  // same dispatch as the library's LaunchStep
-      tet::env_step<W, C, 2, 10>(col, m, action ? action[i] : -1, action == nullptr, tab, kHoleLut10, scratch, 1,
+      tet::env_step<W, C, 2, 10>(col, m, (action && !exhausted) ? action[i] : -1, action == nullptr && !exhausted, tab, kHoleLut10, scratch, 1,
                                  cfg, (uint32_t)(env_offset + i), draw, draw_reset, out);
     else if (sizeof(W) == 8 && cfg.R <= 40)
-      tet::env_step<W, C, 4, 10>(col, m, action ? action[i] : -1, action == nullptr, tab, kHoleLut10, scratch, 1,
+      tet::env_step<W, C, 4, 10>(col, m, (action && !exhausted) ? action[i] : -1, action == nullptr && !exhausted, tab, kHoleLut10, scratch, 1,
                                  cfg, (uint32_t)(env_offset + i), draw, draw_reset, out);
     else
-      tet::env_step<W, C>(col, m, action ? action[i] : -1, action == nullptr, tab, kHoleLut, scratch, 1, cfg,
+      tet::env_step<W, C>(col, m, (action && !exhausted) ? action[i] : -1, action == nullptr && !exhausted, tab, kHoleLut, scratch, 1, cfg,
                           (uint32_t)(env_offset + i), draw, draw_reset, out);
     if (action_out) action_out[i] = out.action;
     if (!out.invalid) {
@@ -197,7 +199,7 @@ void after_impl(const TetrisDesc* desc, const void* cols_, const uint64_t* meta,
       int nh[C];
       const int a = tet::stamp_static<W, C>(col, h, sc, o, nb, pbits);
       int eroded = 0;
-      const int k = tet::clear_lines<W, C>(nb, pbits, &eroded);
+      const int k = tet::clear_lines<W, C>(nb, pbits, a, &eroded);
       tet::heights_of<W, C>(nb, nh);
       float g[8];
       tet::bcts_features<W, C>(nb, nh, R, kHoleLut, a, o.H, eroded, k, g);

@@ -55,7 +55,7 @@ def lockstep_small(device, orc, C, R, pieces, B=1024 + 37, steps=150):
     assert episodes > 0
 
 
-def cfg2_bit_exact(device, orc, B=65536, steps=96):
+def cfg2_bit_exact(device, orc, B=65536, steps=512):
     """BASELINE config 2: 65,536 envs, 10x20, random actions, every output every step."""
     episodes = lockstep(device, orc, 10, 20, B, "default", steps=steps, seed=0)
     assert episodes > B // 64
@@ -378,6 +378,10 @@ def step_many_equals_steps(device, orc, B=700):
                 np.testing.assert_array_equal(rew.cpu().numpy(), o_rew)
             assert torch.equal(a.cols, b.cols) and torch.equal(a.meta, b.meta)
             assert a.stats() == b.stats() and a.step_idx == b.step_idx
+            # the per-step attributes describe the last fused step
+            assert torch.equal(a.obs, b.obs) and torch.equal(a.reward, b.reward) and torch.equal(a.done, b.done)
+            assert torch.equal(a.lines, b.lines) and torch.equal(a.action, b.action)
+            assert torch.equal(a.n_valid, b.n_valid) and torch.equal(a.piece, b.piece)
             np.testing.assert_array_equal(a.boards().cpu().numpy(), ref.cells)
     # greedy policy fused vs unfused
     a = VecTetris(10, 20, 200, device=device, pieces="standard7", auto_reset=True, seed=2)
@@ -409,3 +413,256 @@ def terminal_boards_are_refused(device):
     rep = np.zeros((R + 4, C), np.int_)
     rep[:R + 1, 2] = 1
     assert game.is_game_over(State(rep)) is True
+
+
+DIRS = [-1, -1, -1, -1, -1, -1, 1, -1]  # the reference's usual feature_directions
+
+
+def golden_edges_through_kernels(device, orc, golden_dir):
+    """g4 edge boards (3-line rescue of an over-height piece, 4-line Straight clear, one valid
+    placement, all dead: state.py:33 before :36) through set_boards -> get_after_states(include_terminal)
+    AND one step per valid action, against the fixture recorded from the reference."""
+    from tetris_amd import VecTetris
+    from tetris_amd.tetromino import CATALOGUE
+    g = np.load(os.path.join(golden_dir, "g4_edges.npz"))
+    R, C = 20, 10
+    for name in ("e1_rescue", "e2_tetris", "e3_onevalid", "e4_dead"):
+        board, pi = g[name + "_board"], int(g[name + "_piece"])
+        term = g[name + "_terminal"].astype(bool)
+        feats, kid_cols, ncl = g[name + "_feats"], g[name + "_cols"], g[name + "_n_cleared"]
+        nv = int((~term).sum())
+        B = max(nv, 1)
+        cells = orc.cols_to_cells(np.repeat(board[None], B, axis=0), R + 4)
+        env = VecTetris(C, R, B, device=device, pieces=list(CATALOGUE), auto_reset=False, seed=1)
+        env.set_boards(cells, piece=np.full(B, pi))
+        f, n1, fa, na = env.get_after_states(include_terminal=True)
+        assert int(na[0]) == len(term) and int(n1[0]) == nv == int(env.n_valid[0])
+        np.testing.assert_array_equal(fa[0, :len(term)].cpu().numpy(), feats)
+        np.testing.assert_array_equal(f[0, :nv].cpu().numpy(), feats[~term])
+        assert not f[0, nv:].any()
+        if name == "e4_dead":
+            assert nv == 0
+            env.step(torch.zeros(B, dtype=torch.int32))  # game.py:83: IndexError
+            with pytest.raises(IndexError):
+                env.check()
+            continue
+        # env k plays valid action k
+        obs, rew, done, lines = env.step(torch.arange(B, dtype=torch.int32))
+        env.check()
+        np.testing.assert_array_equal(obs.cpu().numpy(), feats[~term])
+        np.testing.assert_array_equal(lines.cpu().numpy(), ncl[~term])
+        np.testing.assert_array_equal(env.columns().cpu().numpy().astype(np.uint64).T, kid_cols[~term])
+        np.testing.assert_array_equal(rew.cpu().numpy(), ncl[~term].astype(np.int32) - 1 - 100 * done.cpu().numpy())
+    assert int(g["e1_rescue_n_cleared"][0]) == 3 and int(g["e2_tetris_n_cleared"][0]) == 4
+
+
+def golden_placements_through_step(device, orc, golden_dir):
+    """Every NON-terminal g1 placement (all nine pieces, 10x20 / 10x40 / 6x10) played with tetris_hip_step:
+    new board, lowest_free_rows (tetris_hip_decode heights vs the reference's own array), lines and
+    observation against the fixture."""
+    from tetris_amd import VecTetris
+    from tetris_amd.tetromino import CATALOGUE
+    for fname in ("g1_placements_10x20.npz", "g1_placements_10x40.npz", "g1_placements_6x10.npz"):
+        g = np.load(os.path.join(golden_dir, fname))
+        R, C = int(g["R"]), int(g["C"])
+        term = g["terminal"].astype(bool)
+        bix, pc = g["board_ix"], g["piece"]
+        # action index of a placement = its rank among the non-terminal placements of its (board, piece)
+        key = bix.astype(np.int64) * 16 + pc
+        act = np.zeros(len(term), np.int32)
+        for k in np.unique(key):
+            sel = np.nonzero(key == k)[0]
+            act[sel] = np.cumsum(~term[sel]) - 1
+        keep = np.nonzero(~term)[0]
+        B = len(keep)
+        cells = orc.cols_to_cells(g["boards"][bix[keep]], R + 4)
+        env = VecTetris(C, R, B, device=device, pieces=list(CATALOGUE), auto_reset=False, seed=2)
+        env.set_boards(cells, piece=pc[keep].astype(np.int64))
+        # heights of the parent boards (state.py:162-172)
+        want_h = (cells != 0).any(axis=1) * (R + 4 - np.argmax(cells[:, ::-1, :] != 0, axis=1))
+        np.testing.assert_array_equal(env.heights().cpu().numpy(), want_h)
+        obs, rew, done, lines = env.step(torch.from_numpy(act[keep]))
+        env.check()
+        np.testing.assert_array_equal(env.columns().cpu().numpy().astype(np.uint64).T, g["cols"][keep])
+        np.testing.assert_array_equal(env.heights().cpu().numpy(), g["heights"][keep])
+        np.testing.assert_array_equal(lines.cpu().numpy(), g["n_cleared"][keep])
+        np.testing.assert_array_equal(obs.cpu().numpy(), g["feats"][keep])
+
+
+def feature_directions_in_kernels(device, orc, golden_dir, B=500):
+    """The kernels' direct_by multiply (state.py:49-50 through game.py:72,91): step observations and both
+    afterstate matrices of VecTetris(feature_directions=d) == those of the plain env times d, and the g5
+    values recorded from the reference."""
+    from tetris_amd import VecTetris
+    d = torch.tensor(DIRS, dtype=torch.float32, device=device)
+    for rows, pieces in ((20, "default"), (40, "standard7")):
+        a = VecTetris(10, rows, B, device=device, pieces=pieces, auto_reset=True, seed=6)
+        b = VecTetris(10, rows, B, device=device, pieces=pieces, auto_reset=True, seed=6, feature_directions=DIRS)
+        for t in range(50):
+            fa, na, faa, naa = a.get_after_states(include_terminal=True)
+            fb, nb, fba, nba = b.get_after_states(include_terminal=True)
+            assert torch.equal(fa * d, fb) and torch.equal(faa * d, fba) and torch.equal(na, nb)
+            oa, ra, da, la = a.step()
+            ob, rb, db, lb = b.step()
+            assert torch.equal(oa * d, ob) and torch.equal(ra, rb) and torch.equal(a.cols, b.cols)
+        out = b.step_many(5)
+        for k in range(5):
+            oa, _, _, _ = a.step()
+            assert torch.equal(out["obs"][k], oa * d)
+    g = np.load(os.path.join(golden_dir, "g5_dtypes.npz"))
+    np.random.seed(0)
+    rng = orc.NumpyLegacyRNG(0)
+    bag = orc.BagSampler(rng, 2)
+    stream = np.array([[bag.next()], [bag.next()], [0], [0]], np.uint8)
+    e = VecTetris(10, 20, 1, device=device, feature_directions=DIRS, piece_stream=stream)
+    f, nv = e.get_after_states()
+    np.testing.assert_array_equal(f[0, :int(nv[0])].cpu().numpy().astype(np.float64), g["after_directed"])
+    obs, _, _, _ = e.step(torch.zeros(1, dtype=torch.int32))
+    np.testing.assert_array_equal(obs[0].cpu().numpy().astype(np.float64), g["obs_directed"])
+
+
+def action_major_layout(device, B=333):
+    """afterstate_layout="action_major" ([a_max, B, 8] storage) returns the same [B, a_max, 8] values."""
+    from tetris_amd import VecTetris
+    for rows, pieces in ((20, "default"), (40, "standard7")):
+        a = VecTetris(10, rows, B, device=device, pieces=pieces, auto_reset=True, seed=3)
+        b = VecTetris(10, rows, B, device=device, pieces=pieces, auto_reset=True, seed=3,
+                      afterstate_layout="action_major")
+        for t in range(40):
+            fa, na, faa, naa = a.get_after_states(include_terminal=True)
+            fb, nb, fba, nba = b.get_after_states(include_terminal=True)
+            assert fb.shape == fa.shape and not fb.is_contiguous()
+            assert torch.equal(fa, fb) and torch.equal(faa, fba) and torch.equal(na, nb) and torch.equal(naa, nba)
+            a.step()
+            b.step()
+
+
+def state_dict_roundtrip(device, B=600):
+    """state_dict mid-episode -> load_state_dict in another env continues bit-identically (device bag and
+    replay stream)."""
+    from tetris_amd import VecTetris
+    for kw in (dict(), dict(piece_stream=np.random.default_rng(0).integers(0, 2, size=(400, B)).astype(np.uint8))):
+        a = VecTetris(10, 20, B, device=device, auto_reset=True, seed=17, **kw)
+        for t in range(33):
+            a.step()
+        sd = a.state_dict()
+        ref = []
+        for t in range(25):
+            o, r, d, l = a.step()
+            ref.append((o.clone(), r.clone(), d.clone(), l.clone(), a.action.clone(), a.piece.clone()))
+        b = VecTetris(10, 20, B, device=device, auto_reset=True, seed=99, **kw)
+        for t in range(5):
+            b.step()
+        b.load_state_dict(sd)
+        for t in range(25):
+            o, r, d, l = b.step()
+            for x, y in zip(ref[t], (o, r, d, l, b.action, b.piece)):
+                assert torch.equal(x, y)
+        assert torch.equal(a.cols, b.cols) and torch.equal(a.meta, b.meta) and a.stats() == b.stats()
+        with pytest.raises(ValueError):
+            VecTetris(10, 40, B, device=device).load_state_dict(sd)
+
+
+def replay_stream_exhaustion(device, B=70):
+    """An env that runs out of recorded pieces is reported (counted as invalid, left untouched), never
+    continued on a repeated last row."""
+    from tetris_amd import VecTetris
+    L = 12
+    stream = np.random.default_rng(1).integers(0, 2, size=(L, B)).astype(np.uint8)
+    env = VecTetris(10, 20, B, device=device, auto_reset=True, piece_stream=stream)
+    for t in range(L - 2):  # reset took row 0; each step needs cursor + 2 <= L under auto-reset
+        env.step()
+        env.check()
+    before = (env.cols.clone(), env.meta.clone())
+    env.step()
+    assert env.stats()["invalid"] == B
+    assert torch.equal(env.cols, before[0]) and torch.equal(env.meta, before[1])
+    with pytest.raises(IndexError):
+        env.check()
+    # without auto-reset one row per step is enough
+    env = VecTetris(10, 20, B, device=device, auto_reset=False, piece_stream=stream)
+    for t in range(L - 1):
+        env.step(torch.zeros(B, dtype=torch.int32))
+    assert env.stats()["invalid"] == 0
+    env.step(torch.zeros(B, dtype=torch.int32))
+    assert env.stats()["invalid"] == B
+
+
+def device_bag_properties(device, B=1 << 20, steps=48):
+    """tetromino.py:12-22 / game.py:50 for the counter-based device bag, checked on the bag bits of
+    `meta` alone (no oracle mirror): every draw removes a piece that was in the bag, a bag is refilled
+    only when empty (so the draws between refills form a permutation of the piece list), and the bag
+    crosses in-kernel auto-reset and host reset(mask) untouched."""
+    from tetris_amd import VecTetris
+    for pieces, n in (("default", 2), ("standard7", 7),
+                      (["Straight", "Square", "SnakeR", "ThreeLine", "ThreeL", "SnakeL", "T", "RCorner", "LCorner"], 9)):
+        full = (1 << n) - 1
+        env = VecTetris(10, 20 if n != 9 else 10, B if n == 2 else max(B // 16, 4096), device=device, pieces=pieces,
+                        auto_reset=True, seed=123)
+
+        def bag_of():
+            return (env.meta >> 52) & 0xFFF
+
+        def piece_bit():
+            return torch.ones_like(env.meta) << env.piece.to(torch.int64)
+
+        def popc(x):
+            c = torch.zeros_like(x)
+            for b in range(12):
+                c += (x >> b) & 1
+            return c
+
+        bag = bag_of()
+        # construction: one draw from a fresh bag
+        assert torch.equal(bag, full ^ piece_bit())
+        first_counts = torch.bincount(env.piece.to(torch.int64), minlength=n).double()
+        assert (first_counts / first_counts.sum() - 1.0 / n).abs().max() < 0.01 + 2.0 / n / (env.batch_size ** 0.5) * 3
+        n_done = 0
+        for t in range(steps):
+            before = bag
+            _, _, done, _ = env.step()
+            bag = bag_of()
+            pb = piece_bit()
+            assert ((bag & pb) == 0).all() and (bag <= full).all()          # the piece in play left the bag
+            src = torch.where(before == 0, torch.full_like(before, full), before)
+            one = ~done
+            assert torch.equal(bag[one], (src ^ pb)[one]) and ((src & pb) != 0)[one].all()
+            # a finished episode drew twice (game.py:87 then :60): the bag shrank by two pieces, refilling
+            # when it ran empty in between, and was NOT re-initialised
+            two = done
+            if two.any():
+                n_done += int(two.sum())
+                s0 = src[two]
+                s1 = bag[two] | pb[two]            # the bag the second draw saw
+                refilled = s1 == full              # ... a fresh one: the first draw must have emptied its bag
+                assert (popc(s0)[refilled] == 1).all()
+                mid = s1[~refilled]                # otherwise: the first bag minus exactly one piece
+                assert ((mid & ~s0[~refilled]) == 0).all() and (popc(s0[~refilled]) - popc(mid) == 1).all()
+        assert n_done > 0
+        # host reset of some envs: one draw, bag otherwise kept
+        before = bag
+        mask = torch.zeros(env.batch_size, dtype=torch.bool, device=env.device)
+        mask[::3] = True
+        env.reset(mask=mask)
+        bag, pb = bag_of(), piece_bit()
+        src = torch.where(before == 0, torch.full_like(before, full), before)
+        assert torch.equal(bag[mask], (src ^ pb)[mask]) and torch.equal(bag[~mask], before[~mask])
+
+
+def rollouts_pinned_to_reference(device, orc, golden_dir):
+    """g7 part B: tetris_hip_rollouts against returns recorded from the reference's single_rollout
+    (game.py:129-146) on one-piece sets -- the piece sequence is then deterministic -- with the greedy
+    float32 policy: -1 on death at any step, else the rewards of steps 2..length."""
+    from tetris_amd import VecTetris
+    g = np.load(os.path.join(golden_dir, "g7_rollouts.npz"))
+    w = [float(x) for x in g["weights"]]
+    for tag, name in (("one_T_10", "T"), ("one_ThreeL_8", "ThreeL"), ("one_Straight_9", "Straight")):
+        R, length = int(g[tag + "_rows"]), int(g[tag + "_length"])
+        boards, want = g[tag + "_boards"], g[tag + "_returns"]
+        env = VecTetris(10, R, len(boards), device=device, pieces=[name], auto_reset=False, seed=0)
+        env.set_boards(orc.cols_to_cells(boards, R + 4), piece=np.zeros(len(boards), np.int64))
+        for n in (1, 3):  # deterministic game: the mean over n rollouts is the single return
+            got = env.rollouts(length=length, n=n, policy="greedy", weights=w).cpu().numpy()
+            np.testing.assert_array_equal(np.isnan(got), np.isnan(want[:, :env.a_max]))
+            np.testing.assert_array_equal(np.nan_to_num(got, nan=9.0), np.nan_to_num(want[:, :env.a_max], nan=9.0))
+        assert (want == -1).any() and (want < -1).any()

@@ -24,3 +24,11 @@ def test_best_policy(host_backend, golden_dir):
 
 def test_rollouts_and_misc(host_backend):
     fc.rollouts_and_misc("cpu")
+
+
+def test_rollout_script(host_backend, golden_dir):
+    fc.rollout_script("cpu", golden_dir)
+
+
+def test_render_strings(host_backend, golden_dir):
+    fc.render_strings("cpu", golden_dir)

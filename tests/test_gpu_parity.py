@@ -15,7 +15,7 @@ def test_lockstep_small(orc, C, R, pieces):
 
 
 def test_cfg2_batch_65536_bit_exact(orc):
-    """BASELINE config 2: 65,536 envs, 10x20, random actions, every output every step."""
+    """BASELINE config 2: 65,536 envs, 10x20, random actions, T = 512 steps, every output every step."""
     pc.cfg2_bit_exact(DEV, orc)
 
 
@@ -113,3 +113,42 @@ def test_step_many_equals_steps(orc):
 
 def test_terminal_boards_are_refused():
     pc.terminal_boards_are_refused(DEV)
+
+
+def test_golden_edges_through_kernels(orc, golden_dir):
+    pc.golden_edges_through_kernels(DEV, orc, golden_dir)
+
+
+def test_golden_placements_through_step(orc, golden_dir):
+    pc.golden_placements_through_step(DEV, orc, golden_dir)
+
+
+def test_feature_directions_in_kernels(orc, golden_dir):
+    pc.feature_directions_in_kernels(DEV, orc, golden_dir)
+
+
+def test_action_major_layout():
+    pc.action_major_layout(DEV)
+
+
+def test_state_dict_roundtrip():
+    pc.state_dict_roundtrip(DEV)
+
+
+def test_replay_stream_exhaustion():
+    pc.replay_stream_exhaustion(DEV)
+
+
+def test_device_bag_properties_1Mi():
+    """1,048,576 envs (default set): permutation per bag, bag survives auto-reset and reset(mask)."""
+    pc.device_bag_properties(DEV)
+
+
+def test_rollouts_pinned_to_reference(orc, golden_dir):
+    pc.rollouts_pinned_to_reference(DEV, orc, golden_dir)
+
+
+def test_facade_rollout_script_and_render(golden_dir):
+    import facade_cases as fc
+    fc.rollout_script(DEV, golden_dir)
+    fc.render_strings(DEV, golden_dir)

@@ -63,3 +63,35 @@ def test_step_many_equals_steps(host_backend, orc):
 
 def test_terminal_boards_are_refused(host_backend):
     pc.terminal_boards_are_refused("cpu")
+
+
+def test_golden_edges_through_kernels(host_backend, orc, golden_dir):
+    pc.golden_edges_through_kernels(DEV, orc, golden_dir)
+
+
+def test_golden_placements_through_step(host_backend, orc, golden_dir):
+    pc.golden_placements_through_step(DEV, orc, golden_dir)
+
+
+def test_feature_directions_in_kernels(host_backend, orc, golden_dir):
+    pc.feature_directions_in_kernels(DEV, orc, golden_dir, B=120)
+
+
+def test_action_major_layout(host_backend):
+    pc.action_major_layout(DEV, B=65)
+
+
+def test_state_dict_roundtrip(host_backend):
+    pc.state_dict_roundtrip(DEV, B=130)
+
+
+def test_replay_stream_exhaustion(host_backend):
+    pc.replay_stream_exhaustion(DEV)
+
+
+def test_device_bag_properties(host_backend):
+    pc.device_bag_properties(DEV, B=8192, steps=64)
+
+
+def test_rollouts_pinned_to_reference(host_backend, orc, golden_dir):
+    pc.rollouts_pinned_to_reference(DEV, orc, golden_dir)

@@ -398,13 +398,18 @@ TET_HD int stamp_static(const W (&col)[C], const int (&h)[C], int c, const Orien
 
 // state.py:121-143 on bitboards.  F = rows full in every column; each column
 // drops those bits (rows above shift down, zero rows enter at the top).
+// Only rows from the anchor row `a` upwards are looked at: the reference tests its
+// `changed_lines` (rows of the piece, state.py:33,123-126) and nothing else, so a full row that a
+// board set from outside already holds stays where it is -- such a row lies below every piece cell
+// (a column filled at row r has height > r, and the column with bottom offset 0 puts a > r).
+// On boards a game can reach there is no such row and the restriction changes nothing.
 // Returns n_cleared; *eroded = piece cells that sat in cleared rows
 // (state.py:99: sum(cleared_rows * pieces_per_changed_row)).
 template <typename W, int C>
-TET_HD int clear_lines(W (&col)[C], const W (&pbits)[4], int* eroded_cells) {
-  W F = col[0];
+TET_HD int clear_lines(W (&col)[C], const W (&pbits)[4], int a, int* eroded_cells) {
+  W F = (W)((W)~(W)0 << a);
 #pragma unroll
-  for (int i = 1; i < C; ++i) F &= col[i];
+  for (int i = 0; i < C; ++i) F &= col[i];
   int k = popc(F);
   int er = 0;
   if (F != 0) {
@@ -794,7 +799,7 @@ TET_HD void afterstates_env(const W (&col)[C], uint64_t meta, const SetTable& ta
         nb[j] = (c + j < C) ? (W)(col[c + j] | pb) : (W)0;
         nhh[j] = (c + j < C) ? ((j < o.w) ? a + o.b[j] + o.n[j] : h[c + j]) : 0;
       }
-      W F = (W)~(W)0;
+      W F = (W)((W)~(W)0 << a);  // rows of the piece only (see clear_lines)
 #pragma unroll
       for (int i = 0; i < C; ++i) F &= (i >= c && i < c + 4) ? nb[i - c] : col[i];
       const bool fast = ex && F == 0;
@@ -880,7 +885,7 @@ TET_HD void afterstates_env(const W (&col)[C], uint64_t meta, const SetTable& ta
     const uint32_t od = tab.orient[piece][sk].desc;
     const int aa = stamp_dynamic<W, C>(fb, h, sc, od, pbits);
     int eroded = 0;
-    const int kk = clear_lines<W, C>(fb, pbits, &eroded);
+    const int kk = clear_lines<W, C>(fb, pbits, aa, &eroded);
     heights_of<W, C>(fb, fh);
     float f[8];
     bcts_features<W, C, NCH>(fb, fh, R, hole_lut, aa, (int)((od >> 3) & 7u), eroded, kk, f);
@@ -963,7 +968,7 @@ TET_HD void env_step(W (&col)[C], uint64_t& meta, int action, bool use_policy, c
   W pbits[4];
   const int a = stamp_scratch<W, C>(col, scratch, sstride, c, od, pbits);  // tetromino.py get_after_states
   int eroded = 0;
-  const int k = (TET_ABLATE & 8) ? 0 : clear_lines<W, C>(col, pbits, &eroded);   // state.py:33
+  const int k = (TET_ABLATE & 8) ? 0 : clear_lines<W, C>(col, pbits, a, &eroded);   // state.py:33
   heights_of<W, C>(col, h);
   if ((TET_ABLATE & 1) || !cfg.compute_obs) {
 #pragma unroll

@@ -154,6 +154,7 @@ struct StepInputs {
   uint64_t meta;
   int action;
   int draw, draw_reset, cursor;
+  bool exhausted;  // replay stream: this step could run past the last recorded row
   uint4 status;
 };
 
@@ -169,8 +170,12 @@ __device__ __forceinline__ void load_inputs(const StepParams& p, uint32_t i, Ste
   in.draw = -1;
   in.draw_reset = -1;
   in.cursor = 0;
+  in.exhausted = false;
   if (p.stream) {
     in.cursor = p.cursor[ii];
+    // a step consumes one row, two when it ends the episode under auto-reset: an env whose stream
+    // cannot cover that is counted as invalid and left untouched (never a silent replay of the last row)
+    in.exhausted = (int64_t)in.cursor + (p.cfg.auto_reset ? 2 : 1) > p.stream_len || in.cursor < 0;
     int64_t r0 = in.cursor < p.stream_len ? in.cursor : p.stream_len - 1;
     int64_t r1 = in.cursor + 1 < p.stream_len ? in.cursor + 1 : p.stream_len - 1;
     in.draw = p.stream[r0 * p.B + ii];
@@ -228,9 +233,9 @@ __global__ __launch_bounds__(step_block<W>(), (step_waves<W, CR>())) void step_k
   int invalid = 0, done = 0, lines = 0;
   if (live) {
     tet::StepOut out;
-    tet::env_step<W, C, NCH, CR>(in.col, in.meta, in.action, p.action == nullptr, tab, hole_lut,
-                             &lane_cols[0][threadIdx.x], kBlock, p.cfg, p.env_offset + i, in.draw, in.draw_reset,
-                             out);
+    tet::env_step<W, C, NCH, CR>(in.col, in.meta, in.exhausted ? -1 : in.action, p.action == nullptr && !in.exhausted,
+                             tab, hole_lut, &lane_cols[0][threadIdx.x], kBlock, p.cfg, p.env_offset + i, in.draw,
+                             in.draw_reset, out);
     invalid = out.invalid;
     if (p.obs) {
       float4* o4 = reinterpret_cast<float4*>(p.obs);

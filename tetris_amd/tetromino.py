@@ -61,6 +61,21 @@ def placement_of_slot(name, num_columns, slot):
     return k >> 1, c, k & 1
 
 
+_B = "██"
+# what `print(env.current_tetromino)` shows upstream (tetromino.py __repr__ of each class; ThreeLine's is
+# misspelt `__repr` there, so upstream prints the default object repr for it -- here its cells are drawn)
+_UPSTREAM_REPR = {
+    "Straight": "\n" + " ".join([_B] * 4),
+    "Square": "\n%s %s \n%s %s" % (_B, _B, _B, _B),
+    "SnakeR": "\n   %s %s \n%s %s" % (_B, _B, _B, _B),
+    "ThreeL": " %s %s \n%s%s" % (_B, _B, " " * 19, _B),
+    "SnakeL": "\n%s %s \n   %s %s" % (_B, _B, _B, _B),
+    "T": "\n   %s\n%s %s %s" % (_B, _B, _B, _B),
+    "RCorner": "\n%s %s %s\n%s" % (_B, _B, _B, _B),
+    "LCorner": "\n%s %s %s\n      %s" % (_B, _B, _B, _B),
+}
+
+
 class Tetromino:
     """One piece of the set; the stand-in for the reference's piece objects
     (``env.current_tetromino``).  ``tet_ind`` is the index in the env's piece
@@ -81,6 +96,9 @@ class Tetromino:
         return [(b[j] + k, j) for j in range(w) for k in range(n[j])]
 
     def __repr__(self):
+        # the text upstream prints for this piece (tests/golden/g8_render.npz), quirks included
+        if self.name in _UPSTREAM_REPR:
+            return _UPSTREAM_REPR[self.name]
         cells = self.cells()
         hgt = max(r for r, _ in cells) + 1
         wid = max(c for _, c in cells) + 1

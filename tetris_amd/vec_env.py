@@ -92,15 +92,15 @@ class VecTetris:
                 self._lib.check(self.n_planes, "tetris_hip_n_planes")
             self.cols = torch.zeros((self.n_planes, B), dtype=self.word_dtype)
             self.meta = torch.zeros(B, dtype=torch.int64)
-            self.obs = torch.zeros((B, 8), dtype=torch.float32)
-            self.reward = torch.zeros(B, dtype=torch.int32)
-            self._done = torch.zeros(B, dtype=torch.uint8)
-            self.lines = torch.zeros(B, dtype=torch.uint8)
+            self._obs_buf = torch.zeros((B, 8), dtype=torch.float32)
+            self._reward_buf = torch.zeros(B, dtype=torch.int32)
+            self._done_buf = torch.zeros(B, dtype=torch.uint8)
+            self._lines_buf = torch.zeros(B, dtype=torch.uint8)
             self.n_valid = torch.zeros(B, dtype=torch.uint8)
             self.piece = torch.zeros(B, dtype=torch.uint8)
             self.status = torch.zeros(int(self._lib.status_words(B)), dtype=torch.int32)  # [n_waves, 4]
-            self.action = torch.zeros(B, dtype=torch.int32)  # actions drawn by the built-in policy
-        self.done = self._done.view(torch.bool)
+            self._action_buf = torch.zeros(B, dtype=torch.int32)  # actions drawn by the built-in policy
+        self._own_views()
         self._stream = None
         self._cursor = None
         if piece_stream is not None:
@@ -116,6 +116,14 @@ class VecTetris:
         self.reset(init_bag=True)
 
     # -- plumbing -----------------------------------------------------------------
+    def _own_views(self):
+        """Point the per-step attributes (obs, reward, done, lines, action) at this env's own buffers;
+        after step_many they are views of the last row of its trajectory buffers instead."""
+        self.obs, self.reward, self._done, self.lines = self._obs_buf, self._reward_buf, self._done_buf, self._lines_buf
+        self.action = self._action_buf
+        self.done = self._done.view(torch.bool)
+        self._views_own = True
+
     def _hip_stream(self):
         if self.device.type == "cuda":
             return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
@@ -180,6 +188,8 @@ class VecTetris:
         Returns ``(obs [B,8] f32, reward [B] i32, done [B] bool, lines [B] u8)``.
         Out-of-range actions leave that env untouched and are counted; call
         :meth:`check` to turn them into the reference's IndexError."""
+        if not self._views_own:
+            self._own_views()
         a = None
         if action is not None:
             a = torch.as_tensor(action, device=self.device)
@@ -225,9 +235,16 @@ class VecTetris:
                                  self.step_idx, self.env_offset, B, self._hip_stream())
         self._lib.check(rc, "tetris_hip_step_many")
         self.step_idx += K
-        # the per-step views keep describing the latest step
+        # the per-step attributes keep describing the latest step: n_valid / piece (inputs of the next
+        # reset / random_actions) are copied, the outputs become views of the last trajectory row
         self.n_valid.copy_(out["n_valid"][K - 1])
         self.piece.copy_(out["piece"][K - 1])
+        if self.compute_obs:
+            self.obs = out["obs"][K - 1]
+        self.reward, self._done, self.lines = out["reward"][K - 1], out["_done"][K - 1], out["lines"][K - 1]
+        self.action = out["action"][K - 1]
+        self.done = self._done.view(torch.bool)
+        self._views_own = False
         return out
 
     BCTS_WEIGHTS = (-24.04, -19.77, -13.08, -12.63, -10.49, -9.22, 6.6, -1.61)  # game.py:111-118
@@ -273,6 +290,8 @@ class VecTetris:
 
     def random_actions(self, out=None):
         """Uniform random valid action per env (the random-rollout policy)."""
+        if not self._views_own:
+            self._own_views()
         out = self.action if out is None else out
         rc = self._lib.policy_random(_ptr(self.n_valid), _ptr(out), self.seed, self.step_idx, self.env_offset,
                                      self.batch_size, self._hip_stream())
@@ -375,7 +394,8 @@ class VecTetris:
         (game.py:83 raises it immediately; the batch path reports lazily)."""
         n = self.stats()["invalid"]
         if n:
-            raise IndexError("%d out-of-range actions were passed to step()" % n)
+            raise IndexError("%d out-of-range actions were passed to step()%s" % (
+                n, " (or the replay piece_stream ran out of rows)" if self._stream is not None else ""))
 
     # -- checkpoint / snapshot --------------------------------------------------------------------
     def state_dict(self):
