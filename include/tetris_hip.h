@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define TETRIS_HIP_ABI_VERSION 4
+#define TETRIS_HIP_ABI_VERSION 5
 
 #define TETRIS_MAX_PIECES 12
 #define TETRIS_MAX_COLUMNS 10
@@ -155,6 +155,26 @@ int tetris_hip_step(const TetrisDesc* desc, void* cols, uint64_t* meta, const in
                     int32_t* reward, uint8_t* done, uint8_t* lines, uint8_t* n_valid_next,
                     uint8_t* piece_next, uint32_t* status, int32_t auto_reset, uint64_t seed,
                     uint64_t step_idx, int64_t env_offset, int64_t B, void* hip_stream);
+
+/*
+ * The same step as a BOUND CALL, for loops that step one batch many times (game.py:82-92 called
+ * per step of an episode): tetris_hip_step_call_init validates the arguments and prepares, once,
+ * everything that does not change between steps (pointers, geometry, the per-set placement table)
+ * inside `call` -- caller-owned HOST memory of tetris_hip_step_call_size() bytes, 16-byte aligned;
+ * the library still allocates nothing -- and tetris_hip_step_call_run only fills in the action
+ * pointer and the step's hash keys and enqueues the kernel (about a third of the host time of
+ * tetris_hip_step).  Semantics are exactly tetris_hip_step's with the bound arguments; action_out
+ * is written only when action == NULL.  A call object is bound to its buffers: re-init after
+ * re-allocating any of them.  One call object must not be run from two threads at once.
+ */
+int64_t tetris_hip_step_call_size(void);
+int tetris_hip_step_call_init(void* call, const TetrisDesc* desc, void* cols, uint64_t* meta,
+                              int32_t* action_out, const uint8_t* stream, int32_t* cursor,
+                              int64_t stream_len, float* obs, int32_t* reward, uint8_t* done,
+                              uint8_t* lines, uint8_t* n_valid_next, uint8_t* piece_next,
+                              uint32_t* status, int32_t auto_reset, uint64_t seed,
+                              int64_t env_offset, int64_t B);
+int tetris_hip_step_call_run(void* call, const int32_t* action, uint64_t step_idx, void* hip_stream);
 
 /*
  * K consecutive Tetris.step calls of every env in ONE launch, for policies that live in the

@@ -256,6 +256,34 @@ int tetris_host_step(const TetrisDesc* desc, void* cols, uint64_t* meta, const i
   });
 }
 
+// bound step call (mirrors tetris_hip_step_call_*): the arguments are kept and replayed
+struct HostStepCall {
+  TetrisDesc desc;
+  void* cols; uint64_t* meta; int32_t* action_out; const uint8_t* stream; int32_t* cursor; int64_t stream_len;
+  float* obs; int32_t* reward; uint8_t* done; uint8_t* lines; uint8_t* n_valid; uint8_t* piece; uint32_t* status;
+  int32_t auto_reset; uint64_t seed; int64_t env_offset; int64_t B;
+};
+int64_t tetris_host_step_call_size(void) { return (int64_t)sizeof(HostStepCall); }
+int tetris_host_step_call_init(void* call_, const TetrisDesc* desc, void* cols, uint64_t* meta, int32_t* action_out,
+                               const uint8_t* stream, int32_t* cursor, int64_t stream_len, float* obs, int32_t* reward,
+                               uint8_t* done, uint8_t* lines, uint8_t* n_valid_next, uint8_t* piece_next,
+                               uint32_t* status, int32_t auto_reset, uint64_t seed, int64_t env_offset, int64_t B) {
+  int rc = tet::check_desc(desc);
+  if (rc) return rc;
+  if (!call_ || !cols || !meta || !reward || !done || !lines || !n_valid_next) return TETRIS_E_NULL;
+  HostStepCall c = {*desc, cols, meta, action_out, stream, cursor, stream_len, obs, reward, done, lines, n_valid_next,
+                    piece_next, status, auto_reset, seed, env_offset, B};
+  memcpy(call_, &c, sizeof(c));
+  return 0;
+}
+int tetris_host_step_call_run(void* call_, const int32_t* action, uint64_t step_idx, void* unused) {
+  HostStepCall c;
+  memcpy(&c, call_, sizeof(c));
+  return tetris_host_step(&c.desc, c.cols, c.meta, action, action ? nullptr : c.action_out, c.stream, c.cursor,
+                          c.stream_len, c.obs, c.reward, c.done, c.lines, c.n_valid, c.piece, c.status, c.auto_reset,
+                          c.seed, step_idx, c.env_offset, c.B, unused);
+}
+
 int tetris_host_reset(const TetrisDesc* desc, void* cols, uint64_t* meta, const uint8_t* reset_mask,
                       uint8_t* piece_out, uint8_t* n_valid_out, const uint8_t* stream, int32_t* cursor,
                       int64_t stream_len, int32_t init_bag, uint64_t seed, uint64_t step_idx, int64_t env_offset,

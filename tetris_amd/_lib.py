@@ -9,7 +9,7 @@ import os
 from . import build as _build
 
 MAX_PIECES = 12
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class TetrisDesc(ctypes.Structure):
@@ -45,6 +45,10 @@ SIGNATURES = {
     "tetris_hip_reset": [_dp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _u64, _u64, _i64, _i64, _vp],
     "tetris_hip_step": [_dp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _u64, _u64,
                         _i64, _i64, _vp],
+    "tetris_hip_step_call_size": [],
+    "tetris_hip_step_call_init": [_vp, _dp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _u64,
+                                  _i64, _i64],
+    "tetris_hip_step_call_run": [_vp, _vp, _u64, _vp],
     "tetris_hip_step_many": [_dp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _u64, _u64,
                              _i64, _i64, _vp],
     "tetris_hip_afterstates": [_dp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp],
@@ -70,7 +74,7 @@ class _Binding:
                 continue
             fn = getattr(cdll, sym)
             fn.argtypes = argtypes
-            fn.restype = ctypes.c_int64 if name.endswith("status_words") else ctypes.c_int
+            fn.restype = ctypes.c_int64 if name.endswith(("status_words", "step_call_size")) else ctypes.c_int
             setattr(self, name[len("tetris_hip_"):], fn)
         if hasattr(cdll, prefix + "error_string"):
             self._errstr = getattr(cdll, prefix + "error_string")

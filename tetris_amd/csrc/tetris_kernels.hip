@@ -953,6 +953,47 @@ static int fill_step_params(StepParams& p, const TetrisDesc* desc, void* cols, u
   return TETRIS_OK;
 }
 
+// ---- bound step call: everything that does not change between steps is prepared once ------------
+struct TetrisStepCall {
+  uint64_t magic;
+  StepParams p;
+  TetrisDesc desc;
+  uint64_t seed;
+  int32_t* action_out;  // written only when the built-in policy draws the action
+};
+constexpr uint64_t kStepCallMagic = 0x5445545249535343ull;  // "TETRISSC"
+
+int64_t tetris_hip_step_call_size(void) { return (int64_t)sizeof(TetrisStepCall); }
+
+int tetris_hip_step_call_init(void* call_, const TetrisDesc* desc, void* cols, uint64_t* meta, int32_t* action_out,
+                              const uint8_t* stream, int32_t* cursor, int64_t stream_len, float* obs, int32_t* reward,
+                              uint8_t* done, uint8_t* lines, uint8_t* n_valid_next, uint8_t* piece_next,
+                              uint32_t* status, int32_t auto_reset, uint64_t seed, int64_t env_offset, int64_t B) {
+  if (!call_) return TETRIS_E_NULL;
+  TetrisStepCall* call = static_cast<TetrisStepCall*>(call_);
+  call->magic = 0;
+  int rc = fill_step_params(call->p, desc, cols, meta, nullptr, nullptr, stream, cursor, stream_len, obs, reward, done,
+                            lines, n_valid_next, piece_next, status, auto_reset, seed, 0, env_offset, B, B);
+  if (rc) return rc;
+  call->desc = *desc;
+  call->seed = seed;
+  call->action_out = action_out;
+  call->magic = kStepCallMagic;
+  return TETRIS_OK;
+}
+
+int tetris_hip_step_call_run(void* call_, const int32_t* action, uint64_t step_idx, void* hip_stream) {
+  TetrisStepCall* call = static_cast<TetrisStepCall*>(call_);
+  if (!call) return TETRIS_E_NULL;
+  if (call->magic != kStepCallMagic) return TETRIS_E_DESC;
+  StepParams& p = call->p;
+  p.action = action;
+  p.action_out = action ? nullptr : call->action_out;
+  p.cfg.key_step = tet::hash_key(call->seed, step_idx * 4u + 0u);
+  p.cfg.key_policy = tet::hash_key(call->seed, step_idx * 4u + 3u);
+  return dispatch<LaunchStep>(&call->desc, p, (hipStream_t)hip_stream);
+}
+
 int tetris_hip_afterstates(const TetrisDesc* desc, const void* cols, const uint64_t* meta, float* feats,
                            uint8_t* n_valid, float* feats_all, uint8_t* n_all, int64_t env_stride,
                            int64_t row_stride, int64_t B, void* hip_stream) {

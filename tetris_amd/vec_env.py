@@ -113,6 +113,8 @@ class VecTetris:
         self._feats_all = None
         self._n_all = None
         self.step_idx = 0
+        self._step_call = None
+        self._raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None) if self.device.type == "cuda" else None
         self.reset(init_bag=True)
 
     # -- plumbing -----------------------------------------------------------------
@@ -197,15 +199,35 @@ class VecTetris:
                 raise ValueError("action must be [batch_size]")
             if a.dtype != torch.int32 or not a.is_contiguous():
                 a = a.to(torch.int32).contiguous()
-        s, c, n = self._stream_args()
-        rc = self._lib.step(ctypes.byref(self.desc), _ptr(self.cols), _ptr(self.meta), _ptr(a),
-                            _ptr(self.action) if a is None else None, s, c, n,
-                            _ptr(self.obs) if self.compute_obs else None, _ptr(self.reward), _ptr(self._done), _ptr(self.lines), _ptr(self.n_valid),
-                            _ptr(self.piece), _ptr(self.status), int(self.auto_reset), self.seed, self.step_idx,
-                            self.env_offset, self.batch_size, self._hip_stream())
-        self._lib.check(rc, "tetris_hip_step")
+        # bound call (tetris_hip_step_call_*): pointers, geometry and the placement table are prepared once
+        call = self._step_call
+        if call is None:
+            call = self._bind_step_call()
+        if self._raw_stream is not None:
+            stream = self._raw_stream(self.device.index)
+        else:
+            stream = self._hip_stream()
+        rc = self._lib.step_call_run(call, None if a is None else a.data_ptr(), self.step_idx, stream)
+        if rc:
+            self._lib.check(rc, "tetris_hip_step_call_run")
         self.step_idx += 1
         return self.obs, self.reward, self.done, self.lines
+
+    def _bind_step_call(self):
+        size = int(self._lib.step_call_size())
+        buf = ctypes.create_string_buffer(size + 16)
+        addr = (ctypes.addressof(buf) + 15) & ~15
+        s, c, n = self._stream_args()
+        rc = self._lib.step_call_init(addr, ctypes.byref(self.desc), _ptr(self.cols), _ptr(self.meta),
+                                      _ptr(self._action_buf), s, c, n,
+                                      _ptr(self._obs_buf) if self.compute_obs else None, _ptr(self._reward_buf),
+                                      _ptr(self._done_buf), _ptr(self._lines_buf), _ptr(self.n_valid), _ptr(self.piece),
+                                      _ptr(self.status), int(self.auto_reset), self.seed, self.env_offset,
+                                      self.batch_size)
+        self._lib.check(rc, "tetris_hip_step_call_init")
+        self._step_call_buf = buf  # keeps the memory alive
+        self._step_call = addr
+        return addr
 
     def step_many(self, n_steps, policy="random", weights=None, out=None):
         """``n_steps`` consecutive steps in ONE kernel launch with an in-kernel policy ("random":
@@ -415,3 +437,4 @@ class VecTetris:
         if self._cursor is not None and "cursor" in d:
             self._cursor.copy_(d["cursor"])
         self.step_idx, self.seed = int(d["step_idx"]), int(d["seed"])
+        self._step_call = None  # the bound call holds the seed
