@@ -21,10 +21,11 @@
  * Data layout (all [..] are element counts; B = batch)
  *  cols  : column bitboards: bit r of a column = cell (row r, column c), row 0 =
  *          bottom, rows 0..R+3 stored (game.py:56, state.py:27-30).  Word = uint32 if
- *          R+4 <= 31, uint64 if R+4 <= 63 (TetrisDesc.word_bytes).  Stored plane-major,
- *          word[tetris_hip_n_planes(desc)][B]: one plane per column, or -- when the
- *          stored rows fit three quarters of the word -- the columns bit-packed four to
- *          three words (see tetris_hip_n_planes below).
+ *          R+4 <= 31, uint64 if R+4 <= 63 (TetrisDesc.word_bytes).  Stored tile-major,
+ *          word[ceil(B/64)][tetris_hip_n_planes(desc)][64]: envs in tiles of 64 (one
+ *          wavefront), the planes of a tile back to back; one plane per column, or -- when
+ *          the stored rows fit three quarters of the word -- the columns bit-packed four to
+ *          three words (see tetris_hip_n_planes / tetris_hip_board_words below).
  *  meta  : uint64[B] per-env control word:
  *            bits  0-47 valid mask: four C-bit fields, field 2L + o (loop L,
  *                       orientation o of tetromino.py's enumeration), bit c = left
@@ -61,7 +62,7 @@ enum {
   TETRIS_E_COLUMNS = -3,     /* num_columns not built into this library */
   TETRIS_E_ROWS = -4,        /* num_rows outside [4, 59] */
   TETRIS_E_PIECES = -5,      /* bad piece list */
-  TETRIS_E_BATCH = -6,       /* B <= 0 (tetris_hip_step: or B > 2^26 - 1 envs per call) */
+  TETRIS_E_BATCH = -6,       /* B <= 0 (tetris_hip_step: or B beyond ~53 M envs per call: 32-bit byte offsets) */
   TETRIS_E_STREAM = -7,      /* replay stream given without cursor / length */
   TETRIS_E_STRIDE = -8       /* afterstate strides not multiples of 4 floats / too small / matrix beyond 2^32 float4 */
 };
@@ -85,13 +86,17 @@ typedef struct TetrisDesc {
 enum { TETRIS_STATUS_INVALID = 0, TETRIS_STATUS_EPISODES = 1, TETRIS_STATUS_LINES = 2, TETRIS_STATUS_STEPS = 3 };
 int64_t tetris_hip_status_words(int64_t B);
 
-/* Board storage.  `cols` is plane-major: word_bytes-wide words planes[p][env], p < n_planes.
+/* Board storage.  `cols` is tile-major: word_bytes-wide words words[tile][p][lane] with tile =
+ * env / 64, lane = env % 64, p < n_planes -- the state of one wavefront's 64 envs is one contiguous
+ * record of n_planes * 64 words; the last tile is padded to 64 lanes.
  * When the stored rows num_rows + 4 fit three quarters of the word (24 bits of 4-byte, 48 bits of
  * 8-byte words: e.g. 10x20 and 10x40) the columns are 24- / 48-bit fields of one bit string, four
  * columns per three words, and ten columns take eight planes; otherwise plane c = column c.  The
- * caller allocates word_bytes * tetris_hip_n_planes(desc) * B bytes and treats them as opaque:
- * tetris_hip_decode / tetris_hip_encode convert to and from the reference layout. */
+ * caller allocates word_bytes * tetris_hip_board_words(desc, B) bytes (16-byte aligned) and treats
+ * them as opaque: tetris_hip_decode / tetris_hip_encode convert to and from the reference layout.
+ * A shard of whole tiles (a multiple of 64 envs) is a contiguous slice of the batch's storage. */
 int tetris_hip_n_planes(const TetrisDesc* desc);
+int64_t tetris_hip_board_words(const TetrisDesc* desc, int64_t B);
 
 int tetris_hip_version(void);
 const char* tetris_hip_error_string(int code);

@@ -263,6 +263,11 @@ struct HostStepCall {
   float* obs; int32_t* reward; uint8_t* done; uint8_t* lines; uint8_t* n_valid; uint8_t* piece; uint32_t* status;
   int32_t auto_reset; uint64_t seed; int64_t env_offset; int64_t B;
 };
+int64_t tetris_host_board_words(const TetrisDesc* desc, int64_t B) {
+  const int rc = tet::check_desc(desc);
+  if (rc) return rc;
+  return tet::board_words(B, tet::n_planes(desc->num_columns, tet::board_packed(desc->word_bytes, desc->num_rows)));
+}
 int64_t tetris_host_step_call_size(void) { return (int64_t)sizeof(HostStepCall); }
 int tetris_host_step_call_init(void* call_, const TetrisDesc* desc, void* cols, uint64_t* meta, int32_t* action_out,
                                const uint8_t* stream, int32_t* cursor, int64_t stream_len, float* obs, int32_t* reward,
@@ -500,8 +505,8 @@ int tetris_host_decode(const TetrisDesc* desc, const void* cols, int8_t* cells, 
   for (int64_t i = 0; i < B; ++i)
     for (int c = 0; c < C; ++c) {
       uint64_t x = desc->word_bytes == 4
-                       ? tet::load_column_rt<uint32_t>(static_cast<const uint32_t*>(cols), B, i, c, packed)
-                       : tet::load_column_rt<uint64_t>(static_cast<const uint64_t*>(cols), B, i, c, packed);
+                       ? tet::load_column_rt<uint32_t>(static_cast<const uint32_t*>(cols), B, i, c, C, packed)
+                       : tet::load_column_rt<uint64_t>(static_cast<const uint64_t*>(cols), B, i, c, C, packed);
       if (heights) heights[i * C + c] = tet::bitlen(x);
       if (cells)
         for (int r = 0; r < rows; ++r) cells[(i * rows + r) * C + c] = (int8_t)((x >> r) & 1);

@@ -162,7 +162,7 @@ def sharding_equals_single_batch(device, B=2048):
         whole.step(a)
         lo.step(a[:B // 2].contiguous())
         hi.step(a[B // 2:].contiguous())
-    assert torch.equal(whole.cols, torch.cat([lo.cols, hi.cols], dim=1))
+    assert torch.equal(whole.cols, torch.cat([lo.cols, hi.cols], dim=0))
     assert torch.equal(whole.obs, torch.cat([lo.obs, hi.obs]))
     assert torch.equal(whole.meta, torch.cat([lo.meta, hi.meta]))
 

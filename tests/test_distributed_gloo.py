@@ -54,6 +54,6 @@ def test_two_rank_shards_match_single_process(tmp_path, host_backend):
         assert torch.equal(a, b)
     assert torch.equal(g["totals"], whole.totals())
     parts = [torch.load(os.path.join(tmp_path, "rank%d.pt" % r)) for r in range(world)]
-    assert torch.equal(torch.cat([p["cols"] for p in parts], dim=1), whole.cols)
+    assert torch.equal(torch.cat([p["cols"] for p in parts], dim=0), whole.cols)
     assert torch.equal(torch.cat([p["obs"] for p in parts]), whole.obs)
     assert int(g["totals"][1]) > 0

@@ -42,6 +42,7 @@ SIGNATURES = {
     "tetris_hip_n_placements": [_i32, _i32],
     "tetris_hip_status_words": [_i64],
     "tetris_hip_n_planes": [_dp],
+    "tetris_hip_board_words": [_dp, _i64],
     "tetris_hip_reset": [_dp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _u64, _u64, _i64, _i64, _vp],
     "tetris_hip_step": [_dp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _u64, _u64,
                         _i64, _i64, _vp],
@@ -74,7 +75,7 @@ class _Binding:
                 continue
             fn = getattr(cdll, sym)
             fn.argtypes = argtypes
-            fn.restype = ctypes.c_int64 if name.endswith(("status_words", "step_call_size")) else ctypes.c_int
+            fn.restype = ctypes.c_int64 if name.endswith(("status_words", "step_call_size", "board_words")) else ctypes.c_int
             setattr(self, name[len("tetris_hip_"):], fn)
         if hasattr(cdll, prefix + "error_string"):
             self._errstr = getattr(cdll, prefix + "error_string")

@@ -45,6 +45,20 @@ constexpr int step_waves() { return TET_STEP_WAVES ? TET_STEP_WAVES : (sizeof(W)
 template <typename W>
 constexpr int step_block() { return TET_STEP_BLOCK ? TET_STEP_BLOCK : (sizeof(W) == 4 ? 512 : 256); }
 
+// Diagnostic build only (-DTET_STAMPS=1, tools/timeline.py): every workgroup of the step kernel
+// records when it started, when its loads had landed, when it began to store and when it ended
+// (s_memrealtime, 100 MHz) plus where it ran.  Never compiled into the product library.
+#ifndef TET_STAMPS
+#define TET_STAMPS 0
+#endif
+#if TET_STAMPS
+constexpr int kStampWgs = 16384, kStampWords = 6;
+__device__ uint64_t g_stamps[kStampWgs * kStampWords];
+#define TET_STAMP(slot) do { if (threadIdx.x == 0 && blockIdx.x < kStampWgs) g_stamps[blockIdx.x * kStampWords + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define TET_STAMP(slot) ((void)0)
+#endif
+
 // ---- kernels ------------------------------------------------------------------
 
 // feature tables (tools/gen_feature_lut.py): byte tables for hole depth and wells (28 KiB), copied
@@ -105,8 +119,7 @@ __device__ __forceinline__ unsigned wave_sum(int value_bits, int v) {
 }
 
 struct StepParams {
-  void* cols;
-  void* plane[tet::kMaxCols];  // cols + c * B, precomputed so each plane base sits in SGPRs
+  void* cols;              // tile-major board words (tet::plane_index)
   uint64_t* meta;
   const int32_t* action;   // NULL: built-in uniform random policy
   int32_t* action_out;     // optional: the action each env played
@@ -139,12 +152,19 @@ __device__ __forceinline__ void st_off(T* base, uint32_t byte_off, T v) {
 }
 
 // The board of env i goes back to its planes (packed storage: tet::pack_board).
+// byte offset of (env i, plane 0) in the tile-major storage: < 2^32 for every batch the C-ABI accepts
+template <typename W, int NP>
+__device__ __forceinline__ uint32_t record_off(uint32_t i) {
+  return ((i >> 6) * (uint32_t)(NP * 64) + (i & 63u)) * (uint32_t)sizeof(W);
+}
 template <typename W, int C, bool PACK>
 __device__ __forceinline__ void store_planes(const StepParams& p, uint32_t i, const W (&col)[C]) {
-  W w[tet::n_planes(C, PACK)];
+  constexpr int NP = tet::n_planes(C, PACK);
+  W w[NP];
   tet::pack_board<W, C, PACK>(col, w);
+  const uint32_t off = record_off<W, NP>(i);
 #pragma unroll
-  for (int q = 0; q < tet::n_planes(C, PACK); ++q) st_off(static_cast<W*>(p.plane[q]), i * (uint32_t)sizeof(W), w[q]);
+  for (int q = 0; q < NP; ++q) st_off(static_cast<W*>(p.cols), off + (uint32_t)(q * 64 * sizeof(W)), w[q]);
 }
 
 // Everything one lane reads for one env.
@@ -161,9 +181,11 @@ struct StepInputs {
 template <typename W, int C, bool PACK>
 __device__ __forceinline__ void load_inputs(const StepParams& p, uint32_t i, StepInputs<W, C>& in) {
   const uint32_t ii = i < p.B ? i : 0;
-  W w[tet::n_planes(C, PACK)];
+  constexpr int NP = tet::n_planes(C, PACK);
+  W w[NP];
+  const uint32_t off = record_off<W, NP>(ii);
 #pragma unroll
-  for (int q = 0; q < tet::n_planes(C, PACK); ++q) w[q] = ld_off(static_cast<const W*>(p.plane[q]), ii * (uint32_t)sizeof(W));
+  for (int q = 0; q < NP; ++q) w[q] = ld_off(static_cast<const W*>(p.cols), off + (uint32_t)(q * 64 * sizeof(W)));
   tet::unpack_board<W, C, PACK>(w, in.col);
   in.meta = ld_off(p.meta, ii * 8u);
   in.action = p.action ? ld_off(p.action, ii * 4u) : -1;
@@ -203,6 +225,7 @@ __global__ __launch_bounds__(step_block<W>(), (step_waves<W, CR>())) void step_k
   // Issue every global load of this lane first (board, meta, action, counters, its share of the
   // two tables) so that one memory latency covers them all; only then fill LDS and barrier.
   constexpr bool PACK = NCH != 0 && !TET_NO_PACK;  // the launchers pick a counted-chunk variant exactly for packed boards
+  TET_STAMP(0);
   StepInputs<W, C> in;
   load_inputs<W, C, PACK>(p, i, in);
   {
@@ -229,6 +252,7 @@ __global__ __launch_bounds__(step_block<W>(), (step_waves<W, CR>())) void step_k
       if ((int)threadIdx.x + q * kBlock < kTabWords) reinterpret_cast<uint32_t*>(&tab)[threadIdx.x + q * kBlock] = tw[q];
     __syncthreads();
   }
+  TET_STAMP(1);
   W* cols = static_cast<W*>(p.cols);
   int invalid = 0, done = 0, lines = 0;
   if (live) {
@@ -237,6 +261,7 @@ __global__ __launch_bounds__(step_block<W>(), (step_waves<W, CR>())) void step_k
                              tab, hole_lut, &lane_cols[0][threadIdx.x], kBlock, p.cfg, p.env_offset + i, in.draw,
                              in.draw_reset, out);
     invalid = out.invalid;
+    TET_STAMP(2);
     if (p.obs) {
       float4* o4 = reinterpret_cast<float4*>(p.obs);
       st_off(o4, i * 32u, make_float4(out.obs[0], out.obs[1], out.obs[2], out.obs[3]));
@@ -270,6 +295,15 @@ __global__ __launch_bounds__(step_block<W>(), (step_waves<W, CR>())) void step_k
       st_off(reinterpret_cast<uint4*>(p.status), (i >> 6) * 16u, v);
     }
   }
+#if TET_STAMPS
+  __syncthreads();
+  if (threadIdx.x == 0 && blockIdx.x < kStampWgs) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores have left the CU
+    g_stamps[blockIdx.x * kStampWords + 3] = __builtin_amdgcn_s_memrealtime();
+    g_stamps[blockIdx.x * kStampWords + 4] = __builtin_amdgcn_s_getreg(63492);  // HW_REG_HW_ID
+    g_stamps[blockIdx.x * kStampWords + 5] = __builtin_amdgcn_s_getreg(63508);  // HW_REG_XCC_ID
+  }
+#endif
 }
 
 struct StepManyParams {
@@ -396,7 +430,7 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const ResetParams p) {
   if (p.reset_mask && !p.reset_mask[i]) return;
   W* cols = static_cast<W*>(p.cols);
 #pragma unroll
-  for (int q = 0; q < tet::n_planes(C, PACK); ++q) cols[(int64_t)q * p.B + i] = 0;  // game.py:55-58
+  for (int q = 0; q < tet::n_planes(C, PACK); ++q) cols[tet::plane_index(i, q, tet::n_planes(C, PACK))] = 0;  // game.py:55-58
   uint32_t bag = p.init_bag ? 0u : tet::meta_bag(p.meta[i]);
   int piece;
   if (p.stream) {
@@ -664,7 +698,7 @@ __global__ __launch_bounds__(kBlock) void decode_kernel(const W* __restrict__ co
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= B) return;
   for (int c = 0; c < C; ++c) {
-    const W x = tet::load_column_rt<W>(cols, B, i, c, packed);
+    const W x = tet::load_column_rt<W>(cols, B, i, c, C, packed);
     if (heights) heights[i * C + c] = tet::bitlen(x);
     if (cells)
       for (int r = 0; r < rows; ++r) cells[(i * rows + r) * C + c] = (int8_t)((x >> r) & 1);
@@ -802,6 +836,13 @@ extern "C" {
 
 int tetris_hip_version(void) { return TETRIS_HIP_ABI_VERSION; }
 
+#if TET_STAMPS
+int tetris_debug_read_stamps(uint64_t* dst, int n_wgs) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_stamps), sizeof(uint64_t) * kStampWords * (size_t)n_wgs, 0,
+                                  hipMemcpyDeviceToHost);
+}
+#endif
+
 const char* tetris_hip_error_string(int code) {
   switch (code) {
     case TETRIS_OK: return "ok";
@@ -829,6 +870,13 @@ int tetris_hip_n_planes(const TetrisDesc* desc) {
   const int rc = check_desc(desc);
   if (rc) return rc;
   return tet::n_planes(desc->num_columns, tet::board_packed(desc->word_bytes, desc->num_rows));
+}
+
+int64_t tetris_hip_board_words(const TetrisDesc* desc, int64_t B) {
+  const int rc = check_desc(desc);
+  if (rc) return rc;
+  if (B <= 0) return TETRIS_E_BATCH;
+  return tet::board_words(B, tet::n_planes(desc->num_columns, tet::board_packed(desc->word_bytes, desc->num_rows)));
 }
 
 int64_t tetris_hip_status_words(int64_t B) {
@@ -921,11 +969,9 @@ static int fill_step_params(StepParams& p, const TetrisDesc* desc, void* cols, u
   if (rc) return rc;
   if (!cols || !meta || !reward || !done || !lines || !n_valid_next) return TETRIS_E_NULL;
   if (B <= 0 || max_elems > 0x7FFFFFFF / 32) return TETRIS_E_BATCH;  // every byte offset (<= 32 B/element) fits 32 bits
+  if ((B + 63) / 64 * 64 * (int64_t)tet::kMaxCols * 8 > 0xFFFFFFFFll) return TETRIS_E_BATCH;  // ... and so do the board records
   if (stream && (!cursor || stream_len <= 0)) return TETRIS_E_STREAM;
   p.cols = cols;
-  const int n_planes = tet::n_planes(desc->num_columns, tet::board_packed(desc->word_bytes, desc->num_rows));
-  for (int c = 0; c < tet::kMaxCols; ++c)
-    p.plane[c] = static_cast<char*>(cols) + (size_t)(c < n_planes ? c : 0) * (size_t)B * desc->word_bytes;
   p.meta = meta;
   p.action = action;
   p.action_out = action_out;

@@ -85,12 +85,15 @@ class VecTetris:
 
         B, dev = self.batch_size, self.device
         with torch.device(dev):
-            # plane-major column bitboards, opaque: one plane per column, or bit-packed four columns to
-            # three words when the stored rows fit three quarters of the word (tetris_hip_n_planes)
+            # tile-major column bitboards [ceil(B/64), n_planes, 64], opaque: one plane per column, or
+            # bit-packed four columns to three words when the stored rows fit three quarters of the word
+            # (tetris_hip_n_planes / tetris_hip_board_words)
             self.n_planes = int(self._lib.n_planes(ctypes.byref(self.desc)))
             if self.n_planes <= 0:
                 self._lib.check(self.n_planes, "tetris_hip_n_planes")
-            self.cols = torch.zeros((self.n_planes, B), dtype=self.word_dtype)
+            self.n_tiles = (B + 63) // 64
+            assert int(self._lib.board_words(ctypes.byref(self.desc), B)) == self.n_tiles * self.n_planes * 64
+            self.cols = torch.zeros((self.n_tiles, self.n_planes, 64), dtype=self.word_dtype)
             self.meta = torch.zeros(B, dtype=torch.int64)
             self._obs_buf = torch.zeros((B, 8), dtype=torch.float32)
             self._reward_buf = torch.zeros(B, dtype=torch.int32)
@@ -368,7 +371,7 @@ class VecTetris:
         """The boards as one bitboard per column, int64 [C, B] (bit r = cell (row r, column c)):
         the unpacked view of ``cols`` (debugging / tests; the kernels work on ``cols``)."""
         C, W = self.num_columns, 8 * self.desc.word_bytes
-        planes = self.cols.to(torch.int64)
+        planes = self.cols.permute(1, 0, 2).reshape(self.n_planes, -1)[:, :self.batch_size].to(torch.int64)
         if W == 32:
             planes = planes & 0xFFFFFFFF
         if self.n_planes == C:
