@@ -27,10 +27,10 @@
  *          the stored rows fit three quarters of the word -- the columns bit-packed four to
  *          three words (see tetris_hip_n_planes / tetris_hip_board_words below).
  *  meta  : uint64[B] per-env control word:
- *            bits  0-47 valid mask: four C-bit fields, field 2L + o (loop L,
- *                       orientation o of tetromino.py's enumeration), bit c = left
- *                       column c; action k (game.py:69,83) counts the set bits of
- *                       fields 0,1 interleaved by column, then of fields 2,3
+ *            bits  0-47 valid mask: four 12-bit fields, field 2L + o (loop L,
+ *                       orientation o of tetromino.py's enumeration) at bit 12 (2L + o),
+ *                       bit c of a field = left column c; action k (game.py:69,83) counts
+ *                       the set bits of fields 0,1 interleaved by column, then of fields 2,3
  *            bits 48-51 current piece (index into the piece list, game.py:38-39)
  *            bits 52-63 bag: list indices still to be drawn (tetromino.py:12-22)
  */

@@ -190,7 +190,7 @@ void after_impl(const TetrisDesc* desc, const void* cols_, const uint64_t* meta,
     bool consistent = true;
     tet::afterstates_env<W, C, 0>(col, meta[i], tab, kHoleLut, R, [&](bool has, int sk, int sc, float (&f)[8]) {
           if (!has) return;
-      const int s = C * sk + sc;
+      const int s = tet::mask_bit(sk, sc);
       // cross-checks (test harness only): (1) the incremental features against the full
       // evaluation of the same placement, (2) the cached mask against the direct terminal test
       const tet::Orient o = tet::unpack_orient(tab.orient[piece][sk].desc);
@@ -354,7 +354,7 @@ int tetris_host_policy_greedy(const TetrisDesc* desc, const void* cols_, const u
           if (!has) return;
         const float v = tet::fitness_of(f, w);
         if (fall) fall[tet::row_of_slot<C>(full, sk, sc)] = v;
-        if ((valid >> (C * sk + sc)) & 1) {
+        if ((valid >> tet::mask_bit(sk, sc)) & 1) {
           const int row = tet::row_of_slot<C>(valid, sk, sc);
           if (best_row < 0 || v > best || (v == best && row < best_row)) {
             best = v;
@@ -441,7 +441,7 @@ int tetris_host_step_many(const TetrisDesc* desc, void* cols_, uint64_t* meta, i
           int best_row = -1;
           tet::afterstates_env<W, C, 0>(col, m, tab, kHoleLut, cfg.R, [&](bool has, int sk, int sc, float (&f)[8]) {
           if (!has) return;
-            if ((valid >> (C * sk + sc)) & 1) {
+            if ((valid >> tet::mask_bit(sk, sc)) & 1) {
               const float v = tet::fitness_of(f, w);
               const int row = tet::row_of_slot<C>(valid, sk, sc);
               if (best_row < 0 || v > best || (v == best && row < best_row)) {

@@ -212,13 +212,16 @@ TET_HD void store_columns_rt(W* planes, int64_t /*B*/, int64_t i, const W* col, 
 }
 
 // ---- meta word ------------------------------------------------------------
-// bits 0-47  valid mask: four C-bit fields, field k = 2L + o (loop L, orientation o of
-//            tetromino.py's enumeration), bit c of a field = left column c.  The reference
-//            enumerates (L, c, o) in that order, so action k walks fields 0 and 1 interleaved
-//            by column, then fields 2 and 3 (slot_of_action)
+// bits 0-47  valid mask: four 12-bit fields (the low C bits used), field k = 2L + o (loop L,
+//            orientation o of tetromino.py's enumeration) at bit 12k, bit c of a field = left
+//            column c.  The reference enumerates (L, c, o) in that order, so action k walks fields
+//            0 and 1 interleaved by column, then fields 2 and 3 (slot_of_action).  The fixed
+//            12-bit stride keeps every 4-column group of a field inside one nibble (table decode).
 // bits 48-51 current piece (list index, game.py:38-39)
 // bits 52-63 bag: list indices still to be drawn (tetromino.py:12-22)
 constexpr uint64_t kMaskBits = (1ull << 48) - 1;
+constexpr int kFieldStride = 12;
+TET_HD constexpr int mask_bit(int k, int c) { return kFieldStride * k + c; }
 TET_HD uint64_t meta_pack(uint64_t mask, int piece, uint32_t bag) {
   return (mask & kMaskBits) | ((uint64_t)(piece & 15) << 48) | ((uint64_t)(bag & 0xFFF) << 52);
 }
@@ -300,6 +303,19 @@ TET_HD int bag_draw(uint32_t& bag, int n_pieces, uint32_t r16) {
   return pos;
 }
 
+// the same draw through the nibble select table (LutLayout::kSelNib)
+TET_HD int bag_draw_lut(uint32_t& bag, int n_pieces, uint32_t r16, const uint8_t* sel_nib) {
+  if (bag == 0) bag = (1u << n_pieces) - 1u;
+  int k = scale16(r16, popc(bag));
+  const int c0 = popc(bag & 0xFu), c1 = c0 + popc(bag & 0xF0u);
+  const int grp = (k >= c0) + (k >= c1);
+  k -= grp == 0 ? 0 : (grp == 1 ? c0 : c1);
+  const uint32_t nib = (bag >> (4 * grp)) & 15u;
+  const int pos = 4 * grp + (int)sel_nib[nib * 4u + (uint32_t)k];
+  bag &= ~(1u << pos);
+  return pos;
+}
+
 // ---- per-set table staged in LDS -------------------------------------------
 // One entry per (piece of the set, orientation slot k = 2L + o).  Every valid_mask field has a
 // whole word to itself on purpose: the kernels are integer-VALU bound while the LDS pipe idles,
@@ -339,7 +355,10 @@ struct LutLayout {
   static constexpr int kHoleEntries = 1 << (CR + 1), kWellsEntries = 1 << CR;
   static constexpr int kHoleA = 0, kHoleU = kHoleEntries, kWellsS = 2 * kHoleEntries;
   static constexpr int kWellsLead = kWellsS + kWellsEntries, kWellsTrail = kWellsLead + kWellsEntries;
-  static constexpr int kBytes = kWellsTrail + kWellsEntries;
+  // select tables (the same in every set): k-th placement of a 4-column group of one loop's two
+  // orientation fields in the reference's order; k-th set bit of a nibble
+  static constexpr int kSelPair = kWellsTrail + kWellsEntries, kSelNib = kSelPair + 256 * 8;
+  static constexpr int kBytes = kSelNib + 16 * 4;
 };
 constexpr int kFeatureLutBytes = LutLayout<12>::kBytes;
 constexpr int kFeatureLut10Bytes = LutLayout<10>::kBytes;
@@ -354,10 +373,32 @@ TET_HD uint32_t spread2(uint32_t x) {
 }
 
 template <int C>
-TET_HD uint32_t mask_field(uint64_t mask, int k) { return (uint32_t)(mask >> (C * k)) & ((1u << C) - 1u); }
+TET_HD uint32_t mask_field(uint64_t mask, int k) { return (uint32_t)(mask >> (kFieldStride * k)) & ((1u << C) - 1u); }
 
 // action k -> (field kk = 2L + o, column c), given the valid mask (game.py:69,83: index into
-// the non-terminal placements in enumeration order loop, column, orientation)
+// the non-terminal placements in enumeration order loop, column, orientation).  Table form: pick
+// the loop, then the 4-column group by two masked popcounts, then ONE byte of sel_pair decodes the
+// position inside the group -- about a third of the vector instructions of the bit-interleaving
+// form below (the kernels are VALU-bound and the LDS pipe has room).
+template <int C>
+TET_HD void slot_of_action_lut(uint64_t mask, int k, const uint8_t* sel_pair, int& kk, int& c) {
+  static_assert(C <= 12, "three 4-column groups per 12-bit field");
+  constexpr uint32_t kLoopBits = (1u << (2 * kFieldStride)) - 1u;
+  const uint32_t w0 = (uint32_t)mask & kLoopBits, w1 = (uint32_t)(mask >> (2 * kFieldStride)) & kLoopBits;
+  const int n0 = popc(w0);
+  const bool second = k >= n0;
+  const uint32_t w = second ? w1 : w0;
+  int kr = second ? k - n0 : k;
+  constexpr uint32_t kG0 = 0xFu | (0xFu << kFieldStride);  // columns 0-3 of both orientation fields
+  const int c0 = popc(w & kG0), c1 = c0 + popc(w & (kG0 << 4));
+  const int grp = (C > 4 ? (kr >= c0) : 0) + (C > 8 ? (kr >= c1) : 0);
+  kr -= grp == 0 ? 0 : (grp == 1 ? c0 : c1);
+  const uint32_t t = w >> (4 * grp);
+  const uint32_t idx = (t & 15u) | (((t >> kFieldStride) & 15u) << 4);
+  const uint32_t r = sel_pair[idx * 8u + (uint32_t)kr];
+  c = 4 * grp + (int)(r & 3u);
+  kk = (second ? 2 : 0) + (int)(r >> 2);
+}
 template <int C>
 TET_HD void slot_of_action(uint64_t mask, int k, int& kk, int& c) {
   const uint32_t f0 = mask_field<C>(mask, 0), f1 = mask_field<C>(mask, 1);
@@ -655,7 +696,7 @@ TET_HD uint64_t valid_mask(const W (&col)[C], const int (&h)[C], const OrientEnt
     r1 = (rv1 & e.vert4) | (r1 & ~e.vert4);
     const uint32_t r2 = rv2 & e.vert4;
     const uint32_t v = (~i1 | (~(i2 & ~r2) & r1)) & cm;
-    mask |= (uint64_t)v << (C * k);
+    mask |= (uint64_t)v << (kFieldStride * k);
   }
   return mask & fullmask;
 }
@@ -721,9 +762,9 @@ TET_HD int stamp_scratch(W (&col)[C], W* scratch, int sstride, int c, uint32_t d
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int bj = (d >> (6 + 5 * j)) & 3;
-    const int nj = (j < w) ? (int)((d >> (8 + 5 * j)) & 7) : 0;
-    pbits[j] = (W)(lowmask<W>(nj) << (a + bj));
-    TET_SCRATCH_OR(&scratch[idx[j]], pbits[j]);  // j >= w ORs zero (index clamped in range)
+    const int nj = (int)((d >> (8 + 5 * j)) & 7);  // 0 for j >= w (pack_orient leaves those fields empty)
+    pbits[j] = (W)(lowmask<W>(nj) << (a + bj));    // one v_bfm_b32 on 32-bit boards
+    TET_SCRATCH_OR(&scratch[idx[j]], pbits[j]);    // j >= w ORs zero (index clamped in range)
   }
 #pragma unroll
   for (int i = 0; i < C; ++i) col[i] = scratch[i * sstride];
@@ -794,7 +835,7 @@ TET_HD void afterstates_env(const W (&col)[C], uint64_t meta, const SetTable& ta
       const int k = 2 * L + oi;
       const Orient o = unpack_orient(oi ? d1 : d0);
       const bool u1 = oi ? v11 : v01, u2 = oi ? v12 : v02, u3 = oi ? v13 : v03;
-      const int s = C * k + c;
+      const int s = mask_bit(k, c);
       const bool ex = (full >> s) & 1;  // this lane's piece has this placement
       if (!TET_WAVE_ANY(ex)) continue;
       int a = 0;
@@ -895,7 +936,7 @@ TET_HD void afterstates_env(const W (&col)[C], uint64_t meta, const SetTable& ta
     for (int i = 0; i < C; ++i) fb[i] = col[i];
     W pbits[4];
     int fh[C];
-    const int sk = s / C, sc = s - sk * C;
+    const int sk = s / kFieldStride, sc = s - sk * kFieldStride;
     const uint32_t od = tab.orient[piece][sk].desc;
     const int aa = stamp_dynamic<W, C>(fb, h, sc, od, pbits);
     int eroded = 0;
@@ -974,7 +1015,7 @@ TET_HD void env_step(W (&col)[C], uint64_t& meta, int action, bool use_policy, c
   }
   // decode action -> (orientation field, left column): game.py:69,83
   int sk, c;
-  slot_of_action<C>(mask, action, sk, c);
+  slot_of_action_lut<C>(mask, action, hole_lut + LutLayout<CR>::kSelPair, sk, c);
   const uint32_t od = tab.orient[piece][sk].desc;
   const int oH = (od >> 3) & 7;
 
@@ -996,7 +1037,8 @@ TET_HD void env_step(W (&col)[C], uint64_t& meta, int action, bool use_policy, c
   // game.py:87 next piece, :88 is_game_over for THAT piece.  One hash feeds both draws of
   // the step: high 16 bits the step draw, low 16 bits the reset draw.
   const uint32_t rnd = hash_env(cfg.key_step, env);
-  int np = draw >= 0 ? draw : bag_draw(bag, cfg.n_pieces, rnd >> 16);
+  const uint8_t* sel_nib = hole_lut + LutLayout<CR>::kSelNib;
+  int np = draw >= 0 ? draw : bag_draw_lut(bag, cfg.n_pieces, rnd >> 16, sel_nib);
   uint64_t nmask = (TET_ABLATE & 2) ? (tab.fullmask[np] ^ (uint64_t)h[0])
                                     : valid_mask<W, C>(col, h, piece_entries(tab, np), tab.fullmask[np], R);
   int nnv = popc(nmask);
@@ -1007,7 +1049,7 @@ TET_HD void env_step(W (&col)[C], uint64_t& meta, int action, bool use_policy, c
   if (done && cfg.auto_reset) {  // game.py:53-63 on the caller's behalf; the bag survives
 #pragma unroll
     for (int i = 0; i < C; ++i) col[i] = 0;
-    np = draw_reset >= 0 ? draw_reset : bag_draw(bag, cfg.n_pieces, rnd & 0xFFFFu);
+    np = draw_reset >= 0 ? draw_reset : bag_draw_lut(bag, cfg.n_pieces, rnd & 0xFFFFu, sel_nib);
     nmask = tab.fullmask[np];
     nnv = popc(nmask);
   }
@@ -1056,7 +1098,7 @@ TET_HD int rollout_env(const W (&col0)[C], uint64_t meta0, int a0, int length, i
         int best_row = -1;
         afterstates_env<W, C, NCH>(col, meta, tab, hole_lut, R, [&](bool has, int sk, int sc, float (&f)[8]) {
           if (!has) return;
-          if ((valid >> (C * sk + sc)) & 1) {
+          if ((valid >> mask_bit(sk, sc)) & 1) {
             const float v = fitness_of(f, w);
             const int row = row_of_slot<C>(valid, sk, sc);
             if (best_row < 0 || v > best || (v == best && row < best_row)) {

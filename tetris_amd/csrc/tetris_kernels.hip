@@ -351,7 +351,7 @@ __global__ __launch_bounds__(step_block<W>(), (POLICY == 0 ? step_waves<W, CR>()
         int best_row = -1;
         tet::afterstates_env<W, C, NCH>(in.col, in.meta, tab, hole_lut, cfg.R, [&](bool has, int sk, int sc, float (&f)[8]) {
           if (!has) return;
-          if ((valid >> (C * sk + sc)) & 1) {
+          if ((valid >> tet::mask_bit(sk, sc)) & 1) {
             const float v = tet::fitness_of(f, q.w);
             const int row = tet::row_of_slot<C>(valid, sk, sc);
             if (best_row < 0 || v > best || (v == best && row < best_row)) {
@@ -562,7 +562,7 @@ __global__ __launch_bounds__(kBlock, TET_AFTER_WAVES) void afterstates_kernel(co
     // the row of a placement follows the reference's enumeration order (tet::row_of_slot)
     if (p.feats_all)
       store_row_paired(xch, p.feats_all, has, env4 + (uint32_t)tet::row_of_slot<C>(full, sk, sc) * rs4, f);
-    store_row_paired(xch, p.feats, has && ((valid >> (C * sk + sc)) & 1),  // game.py:69
+    store_row_paired(xch, p.feats, has && ((valid >> tet::mask_bit(sk, sc)) & 1),  // game.py:69
                      env4 + (uint32_t)tet::row_of_slot<C>(valid, sk, sc) * rs4, f);
   });
   if (TET_ABLATE & 64) {
@@ -619,7 +619,7 @@ __global__ __launch_bounds__(kBlock) void greedy_kernel(const GreedyParams p) {
           if (!has) return;
     const float v = tet::fitness_of(f, p.w);
     if (fall) fall[tet::row_of_slot<C>(full, sk, sc)] = v;
-    if ((valid >> (C * sk + sc)) & 1) {
+    if ((valid >> tet::mask_bit(sk, sc)) & 1) {
       const int row = tet::row_of_slot<C>(valid, sk, sc);
       if (best_row < 0 || v > best || (v == best && row < best_row)) {
         best = v;

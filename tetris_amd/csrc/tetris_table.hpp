@@ -92,7 +92,7 @@ inline void build_table(const TetrisDesc* d, SetTable* t) {
         OrientEntry* e = &t->orient[i][l * 2 + oi];
         e->desc = pack_orient(p.o[l][oi]);
         pack_mask_fields(p.o[l][oi], e);
-        for (int c = 0; c + p.o[l][oi].w <= C; ++c) full |= 1ull << (C * (2 * l + oi) + c);
+        for (int c = 0; c + p.o[l][oi].w <= C; ++c) full |= 1ull << mask_bit(2 * l + oi, c);
       }
     t->fullmask[i] = full;
   }

@@ -18,12 +18,12 @@ from .vec_env import VecTetris
 
 def _placements_in_action_order(mask, C):
     """(loop, column, orientation) of the set bits of a valid mask in the reference's
-    enumeration order.  Mask layout: four C-bit fields, field 2L + o, bit c."""
+    enumeration order.  Mask layout: four 12-bit fields, field 2L + o at bit 12 (2L + o), bit c."""
     out = []
     for loop in (0, 1):
         for c in range(C):
             for o in (0, 1):
-                if (mask >> (C * (2 * loop + o) + c)) & 1:
+                if (mask >> (12 * (2 * loop + o) + c)) & 1:
                     out.append((loop, c, o))
     return out
 

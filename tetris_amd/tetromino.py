@@ -55,9 +55,9 @@ def n_placements(name, num_columns):
 
 
 def placement_of_slot(name, num_columns, slot):
-    """Bit index of the valid mask (four num_columns-bit fields, field 2*loop + orientation,
+    """Bit index of the valid mask (four 12-bit fields, field 2*loop + orientation at bit 12 * field,
     bit = left column) -> (loop, column, orientation index)."""
-    k, c = divmod(slot, num_columns)
+    k, c = divmod(slot, 12)
     return k >> 1, c, k & 1
 
 

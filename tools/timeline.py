@@ -45,9 +45,14 @@ for rep in range(3):
     for _ in range(5):
         env.step()
     torch.cuda.synchronize()
-    buf = np.zeros((n_wg, 6), np.uint64)
+    buf = np.zeros((n_wg, 20), np.uint64)
     rc = cdll.tetris_debug_read_stamps(buf.ctypes.data_as(ctypes.c_void_p), n_wg)
     assert rc == 0, rc
+    # the persistent kernel launches fewer workgroups than tiles: keep the slots this launch wrote
+    newest = buf[:, 0].max()
+    buf = buf[(buf[:, 0] > 0) & (newest - buf[:, 0] < 100000) & (buf[:, 3] >= buf[:, 0])]
+    n_wg = len(buf)
+    per_tile = buf[:, 6:18].astype(np.int64)
     t = buf[:, :4].astype(np.int64)
     t0 = t[:, 0].min()
     t = (t - t0) * 0.01  # us (100 MHz)
@@ -55,15 +60,16 @@ for rep in range(3):
     cu = (xcc << 16) | (((hw >> 13) & 7) << 8) | (((hw >> 12) & 1) << 4) | ((hw >> 8) & 15)  # xcc, se, sh, cu
     ncu = len(np.unique(cu))
     per_cu = np.bincount(np.unique(cu, return_inverse=True)[1])
-    print("---- rep %d: %d workgroups of %d envs on %d CUs (min/median/max per CU %d/%d/%d)" % (
+    print("---- rep %d: %d workgroups (block %d) on %d CUs (min/median/max per CU %d/%d/%d)" % (
         rep, n_wg, blk, ncu, per_cu.min(), int(np.median(per_cu)), per_cu.max()))
     print("launch span %.2f us (first start -> last end); last start at %.2f us" % (t[:, 3].max(), t[:, 0].max()))
-    for name, d in (("start -> loads landed + LDS filled", t[:, 1] - t[:, 0]), ("compute", t[:, 2] - t[:, 1]),
-                    ("stores issued + drained", t[:, 3] - t[:, 2]), ("whole workgroup", t[:, 3] - t[:, 0])):
+    for name, d in (("start -> tables + first tile in LDS", t[:, 1] - t[:, 0]),
+                    ("-> last tile of wave 0 computed", t[:, 2] - t[:, 1]),
+                    ("-> last stores issued + drained", t[:, 3] - t[:, 2]), ("whole workgroup", t[:, 3] - t[:, 0])):
         print("  %-36s mean %.2f  p10 %.2f  p50 %.2f  p90 %.2f  max %.2f us" % (
             name, d.mean(), *np.percentile(d, [10, 50, 90]), d.max()))
     # workgroups in each phase over time (whole chip), 1 us bins
-    T = int(np.ceil(t[:, 3].max())) + 1
+    T = min(int(np.ceil(t[:, 3].max())) + 1, 400)
     grid = np.arange(T) + 0.5
     rows_ = []
     for a, b in ((0, 1), (1, 2), (2, 3)):
@@ -71,6 +77,17 @@ for rep in range(3):
     print("  t(us)   loading computing storing   (workgroups chip-wide; %d CUs x 3 resident = %d slots)" % (ncu, 3 * ncu))
     for k in range(T):
         print("  %5.1f  %7d %9d %7d" % (grid[k], rows_[0][k], rows_[1][k], rows_[2][k]))
+    # per-tile stamps of wave 0 of every workgroup: compute done / wait passed / stores issued
+    pt = np.where(per_tile > 0, (per_tile - t0) * 0.01, np.nan)
+    for k in range(4):
+        c, w_, st_ = pt[:, 3 * k], pt[:, 3 * k + 1], pt[:, 3 * k + 2]
+        ok = ~np.isnan(c) & (c >= 0) & (c < 1000)
+        if ok.sum() == 0:
+            continue
+        print("  tile %d (%4d wgs): compute done at p10 %.2f p50 %.2f p90 %.2f | wait before stores p50 %.2f max %.2f | "
+              "store issue p50 %.2f max %.2f us" % (k, ok.sum(), *np.percentile(c[ok], [10, 50, 90]),
+                                                    np.median((w_ - c)[ok]), (w_ - c)[ok].max(),
+                                                    np.median((st_ - w_)[ok]), (st_ - w_)[ok].max()))
     # per-CU finish time spread
     fin = np.array([t[cu == c, 3].max() for c in np.unique(cu)])
     print("  per-CU finish: min %.2f  p50 %.2f  max %.2f us" % (fin.min(), np.median(fin), fin.max()))
