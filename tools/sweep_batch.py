@@ -16,7 +16,8 @@ if os.environ.get("SWEEP_LIB"):  # the whole run (allocation included) goes thro
 
 for B in [int(x) for x in (sys.argv[1:] or ["65536", "163840", "327680", "655360", "1048576", "1310720", "2097152",
                                             "4194304"])]:
-    env = VecTetris(10, 20, B, device="cuda", auto_reset=True, seed=0)
+    env = VecTetris(10, int(os.environ.get("SWEEP_ROWS", "20")), B, device="cuda", auto_reset=True, seed=0,
+                    pieces=os.environ.get("SWEEP_PIECES", "default"))
     for t in range(120):
         env.step()
     best = 1e9

@@ -36,7 +36,10 @@ struct Ptrs {
   uint32_t B;
 };
 
-template <int V, int BLK>
+// V7: V0's traffic with NV extra vector instructions per lane between the loads and the stores (four
+// independent chains of xor / add / shift): how memory time and VALU time combine for this access
+// pattern -- max() if they overlap, sum if they do not.
+template <int V, int BLK, int NV = 0>
 __global__ __launch_bounds__(BLK) void traffic(const Ptrs p) {
   constexpr int NP = (V >= 2 && V <= 4) ? 9 : 8;
   const uint32_t i = blockIdx.x * BLK + threadIdx.x;
@@ -61,6 +64,17 @@ __global__ __launch_bounds__(BLK) void traffic(const Ptrs p) {
     extra = lds[(w[0] ^ threadIdx.x) % 602].x;
   }
   uint32_t acc = (uint32_t)meta ^ (uint32_t)(meta >> 32) ^ extra;
+  if (NV > 0) {
+    uint32_t c0 = w[0], c1 = w[1], c2 = w[2], c3 = w[3];
+#pragma unroll 16
+    for (int t = 0; t < NV / 8; ++t) {  // 8 instructions per iteration
+      c0 = (c0 ^ c1) + 0x9E3779B9u;
+      c1 = (c1 >> 3) ^ c2;
+      c2 = (c2 + c3) ^ 0x85EBCA6Bu;
+      c3 = (c3 >> 5) + c0;
+    }
+    acc ^= c0 ^ c1 ^ c2 ^ c3;
+  }
 #pragma unroll
   for (int q = 0; q < NP; ++q) {
     acc = acc * 0x9E3779B1u + w[q];
@@ -125,17 +139,17 @@ __global__ __launch_bounds__(256) void copy4(const float4* __restrict__ src, flo
   if (i < n) dst[i] = src[i];
 }
 
-template <int V, int BLK>
+template <int V, int BLK, int NV = 0>
 float run(const Ptrs& p, int reps) {
   hipEvent_t s, e;
   hipEventCreate(&s);
   hipEventCreate(&e);
   const int grid = (p.B + BLK - 1) / BLK;
-  for (int i = 0; i < 20; ++i) hipLaunchKernelGGL((traffic<V, BLK>), dim3(grid), dim3(BLK), 0, 0, p);
+  for (int i = 0; i < 20; ++i) hipLaunchKernelGGL((traffic<V, BLK, NV>), dim3(grid), dim3(BLK), 0, 0, p);
   float best = 1e9f;
   for (int r = 0; r < 3; ++r) {
     hipEventRecord(s, 0);
-    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((traffic<V, BLK>), dim3(grid), dim3(BLK), 0, 0, p);
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((traffic<V, BLK, NV>), dim3(grid), dim3(BLK), 0, 0, p);
     hipEventRecord(e, 0);
     hipEventSynchronize(e);
     float ms = 0;
@@ -183,6 +197,12 @@ int main(int argc, char** argv) {
     const float us = run<V, BLK>(p, reps);                                                                 \
     printf("V%d blk %3d: %7.2f us  %6.1f B/env  %.2f TB/s\n", V, BLK, us, bytes_of(V), bytes_of(V) * B / us / 1e6); \
   }
+#define RUNV(NV)                                                                                 \
+  {                                                                                              \
+    const float us = run<0, 512, NV>(p, reps);                                                   \
+    printf("V0 blk 512 + %4d VALU/lane: %7.2f us\n", NV, us);                                    \
+  }
+    RUNV(256) RUNV(512) RUNV(768) RUNV(1024) RUNV(1536) RUNV(2048)
     RUN(0, 256) RUN(0, 512) RUN(1, 256) RUN(1, 512) RUN(2, 256) RUN(2, 512) RUN(3, 256) RUN(3, 512) RUN(4, 256)
     RUN(4, 512) RUN(5, 256) RUN(5, 512)
     {
