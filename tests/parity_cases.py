@@ -256,6 +256,9 @@ def edge_geometries(device, orc):
     for C, R, pieces, B in [(10, 4, "default", 130), (10, 27, "standard7", 65), (10, 28, "standard7", 63),
                             (10, 59, "default", 31), (6, 4, "standard7", 1), (8, 27, "default", 257),
                             (6, 59, "standard7", 64),
+                            # every column count the library is built for (5..10), odd ones included
+                            (5, 12, "standard7", 33), (5, 20, "default", 40), (7, 24, "standard7", 50),
+                            (9, 20, "default", 70), (9, 40, "standard7", 30), (5, 30, "standard7", 20),
                             # either side of every kernel-variant switch: 10-row / 12-row table chunks (R = 20 | 21),
                             # chunk borders inside the board (R = 10, 12, 13), compile-time chunk counts of the
                             # u64 kernels (stored rows 36 | 37 and 48 | 49)

@@ -40,7 +40,8 @@ def test_desc_init_and_argument_errors(hip_lib):
     assert hip_lib.desc_init(ctypes.byref(d), 10, 20, ids, 2, None) == 0
     assert (d.word_bytes, d.a_max, d.n_pieces) == (4, 36, 2)
     assert hip_lib.desc_init(ctypes.byref(d), 10, 40, ids, 2, None) == 0 and d.word_bytes == 8
-    assert hip_lib.desc_init(ctypes.byref(d), 11, 20, ids, 2, None) == -3     # TETRIS_E_COLUMNS
+    assert hip_lib.desc_init(ctypes.byref(d), 11, 20, ids, 2, None) == -3     # TETRIS_E_COLUMNS (5..10 are built)
+    assert hip_lib.desc_init(ctypes.byref(d), 4, 20, ids, 2, None) == -3
     assert hip_lib.desc_init(ctypes.byref(d), 10, 3, ids, 2, None) == -4      # TETRIS_E_ROWS
     assert hip_lib.desc_init(ctypes.byref(d), 10, 20, ids, 0, None) == -5     # TETRIS_E_PIECES
     bad = (ctypes.c_int32 * 1)(9)
@@ -55,7 +56,7 @@ def test_desc_init_and_argument_errors(hip_lib):
     assert "NULL" in hip_lib.error_string(-1)
     cols = (ctypes.c_int32 * 16)()
     n = hip_lib.supported_columns(cols, 16)
-    assert 10 in list(cols)[:n]
+    assert list(cols)[:n] == [5, 6, 7, 8, 9, 10]
     assert hip_lib.status_words(1 << 20) == 4 * ((1 << 20) // 64)
 
 
@@ -63,7 +64,7 @@ def test_host_tables_match_library(hip_lib):
     from tetris_amd.tetromino import CATALOGUE, ORIENTATIONS, n_placements
     want = dict(Straight=17, Square=9, SnakeR=17, ThreeLine=18, ThreeL=36, SnakeL=17, T=34, RCorner=34, LCorner=34)
     for i, name in enumerate(CATALOGUE):
-        for C in (6, 8, 10):
+        for C in (5, 6, 7, 8, 9, 10):
             assert hip_lib.n_placements(i, C) == n_placements(name, C)
         assert n_placements(name, 10) == want[name]
         for loop in ORIENTATIONS[name]:

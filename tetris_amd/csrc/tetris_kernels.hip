@@ -22,9 +22,11 @@ using tet::check_desc;
 
 constexpr int kBlock = 256;
 
-// minimum waves per SIMD the step kernel is compiled for (bounds its VGPR budget).  u32 boards:
-// 5 (96 VGPRs, 3 spilled dwords; measured 3 % faster than the unconstrained 100 VGPRs / 4 waves;
-// 27 KiB of LDS per workgroup allow 5 workgroups per CU anyway).  u64 boards need ~136 VGPRs.
+// minimum waves per SIMD the step kernel is compiled for (bounds its VGPR budget).  u32 boards: 5
+// -- the kernel needs 73 VGPRs (80 allocated: 6 waves per SIMD = three 512-env workgroups per CU),
+// no spills.  u64 boards: 103-129 VGPRs (4 / 3 waves per SIMD).  Builds with 7 and 8 waves per SIMD
+// (256-env tiles at 71 VGPRs; 512-env tiles squeezed to 64) were timed in round 2 and are not
+// faster: profiles/r02_experiments/sweep_compacted_mask_and_occupancy_variants.txt.
 #ifndef TET_STEP_WAVES
 #define TET_STEP_WAVES 0
 #endif
@@ -33,9 +35,9 @@ constexpr int step_waves() { return TET_STEP_WAVES ? TET_STEP_WAVES : (sizeof(W)
 
 // envs per workgroup of the step kernel: the feature tables are staged once per workgroup, so a
 // larger tile amortises that L2 -> LDS traffic over more envs.  u32 boards: 512 (8 waves = 2 per
-// SIMD per workgroup, two workgroups per CU; measured 37.9 us against 40.0 us with 256; 320, 640
-// and 1024 are slower: uneven waves per SIMD / one workgroup per CU).  u64 boards keep 256 (their
-// ~136 VGPRs allow 3 waves per SIMD = three 256-env workgroups).
+// SIMD per workgroup, three workgroups per CU; 320, 640 and 1024 are slower: uneven waves per
+// SIMD / one workgroup per CU; 256 is within 1 %).  u64 boards keep 256 (their registers allow
+// 3-4 waves per SIMD = three or four 256-env workgroups).
 #ifndef TET_STEP_BLOCK
 #define TET_STEP_BLOCK 0
 #endif
@@ -207,10 +209,12 @@ __device__ __forceinline__ void load_inputs(const StepParams& p, uint32_t i, Ste
   if (p.status) in.status = ld_off(reinterpret_cast<const uint4*>(p.status), (i >> 6) * 16u);  // this wave's slot
 }
 
-// One tile of envs per workgroup.  (Persistent variants -- a grid-stride loop that prefetches the
-// next tile, or 2 / 4 / 8 tiles per workgroup with the tables staged once -- were measured and
-// are 3-20 % slower: the loop costs registers (94 instead of 73 VGPRs) and hardware dispatch
-// balances the CUs better than a static assignment.)
+// One tile of envs per workgroup.  Persistent variants were measured in both rounds and are not
+// faster: round 1's grid-stride loops (register prefetch, or 2 / 4 / 8 tiles per workgroup) were
+// 3-20 % slower; round 2's per-wavefront loop with LDS-DMA prefetch of the next tile (no load is
+// ever waited for, tables staged once per launch) ties at 1 Mi envs and loses elsewhere -- the SIMD
+// arbitrates by age, so the oldest waves race ahead and the youngest finish the launch alone;
+// evening that out with s_setprio recovers the tie, no more (profiles/r02_experiments/).
 // NCH = number of 12-row chunks of the stored board, fixed at compile time for the common
 // geometries (2: up to 24 stored rows, e.g. 10x20; 4: up to 48, e.g. 10x40), 0 = decide from R.
 template <typename W, int C, int NCH, int CR>

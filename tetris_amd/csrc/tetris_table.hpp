@@ -56,8 +56,9 @@ inline int n_placements(int pid, int C) {
 }
 
 // thresholds: footprint column j needs slack R - h >= need_j = H - b_j.  valid_mask keeps the
-// column sets B_l = {c : slack < l} in 16-bit fields of one 64-bit word; the shift
-// 16*(need_j - 1) + j lines column c + j of level need_j up with bit c.
+// column sets B_l = {c : slack < l} in 10-bit fields of one 64-bit word (level l at bit 10 l); the
+// shift 10*(need_j - 1) + j lines column c + j of level need_j up with bit 10 + c and of level
+// need_j - 1 with bit c.
 inline void pack_mask_fields(const CatOrient& o, OrientEntry* e) {
   int H = 0;
   for (int j = 0; j < o.w; ++j)
@@ -100,7 +101,9 @@ inline void build_table(const TetrisDesc* d, SetTable* t) {
 
 // num_columns values the kernels are instantiated for (one place for the
 // library, the dispatch switch and the CPU test harness)
-#define TET_COLUMNS(X) X(6) X(8) X(10)
+// (5 is the lower bound: with 4 columns a horizontal Straight IS a full row wherever it lands, even in the
+// overflow rows, which the bit-parallel valid mask does not model; 10 the upper one, see valid_mask)
+#define TET_COLUMNS(X) X(5) X(6) X(7) X(8) X(9) X(10)
 
 inline bool columns_supported(int C) {
   switch (C) {
