@@ -54,7 +54,7 @@ constexpr int step_block() { return TET_STEP_BLOCK ? TET_STEP_BLOCK : (sizeof(W)
 #define TET_STAMPS 0
 #endif
 #if TET_STAMPS
-constexpr int kStampWgs = 16384, kStampWords = 6;
+constexpr int kStampWgs = 16384, kStampWords = 20;  // (slots 6.. are per-tile stamps of looping variants; unused here)
 __device__ uint64_t g_stamps[kStampWgs * kStampWords];
 #define TET_STAMP(slot) do { if (threadIdx.x == 0 && blockIdx.x < kStampWgs) g_stamps[blockIdx.x * kStampWords + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else

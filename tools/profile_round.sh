@@ -10,15 +10,17 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 
 # 1. bench lines (N = 1): headline, config 5 shape, 7-piece set, without obs, fused
-timeout -k 10 300 python3 bench.py > $OUT/bench_n1_10x20.json 2> $OUT/bench_n1_10x20.err || exit 1
-timeout -k 10 200 python3 bench.py --no-cpu-baseline --rows 40 > $OUT/bench_n1_10x40.json 2>/dev/null || exit 1
-timeout -k 10 200 python3 bench.py --no-cpu-baseline --pieces standard7 > $OUT/bench_n1_10x20_standard7.json 2>/dev/null || exit 1
-timeout -k 10 200 python3 bench.py --no-cpu-baseline --no-obs > $OUT/bench_n1_10x20_no_obs.json 2>/dev/null || exit 1
-timeout -k 10 200 python3 bench.py --no-cpu-baseline --fuse 20 --steps 1000 --warmup 100 > $OUT/bench_n1_10x20_fuse20.json 2>/dev/null || exit 1
+X="--no-cpu-baseline --no-extras"
+timeout -k 10 200 python3 bench.py $X --rows 40 > $OUT/bench_n1_10x40.json 2>/dev/null || exit 1
+timeout -k 10 200 python3 bench.py $X --pieces standard7 > $OUT/bench_n1_10x20_standard7.json 2>/dev/null || exit 1
+timeout -k 10 200 python3 bench.py $X --no-obs > $OUT/bench_n1_10x20_no_obs.json 2>/dev/null || exit 1
+timeout -k 10 200 python3 bench.py $X --fuse 20 --steps 1000 --warmup 100 > $OUT/bench_n1_10x20_fuse20.json 2>/dev/null || exit 1
 # two env shards per GPU on two HIP streams (the tail of one launch overlaps the ramp of the other)
-timeout -k 10 200 python3 bench.py --no-cpu-baseline --streams 2 > $OUT/bench_n1_10x20_streams2.json 2>/dev/null || exit 1
-timeout -k 10 200 python3 bench.py --no-cpu-baseline --streams 2 --rows 40 > $OUT/bench_n1_10x40_streams2.json 2>/dev/null || exit 1
-timeout -k 10 200 python3 bench.py --no-cpu-baseline --streams 2 --fuse 20 --steps 1000 --warmup 100 > $OUT/bench_n1_10x20_streams2_fuse20.json 2>/dev/null || exit 1
+timeout -k 10 200 python3 bench.py $X --streams 2 > $OUT/bench_n1_10x20_streams2.json 2>/dev/null || exit 1
+timeout -k 10 200 python3 bench.py $X --streams 2 --rows 40 > $OUT/bench_n1_10x40_streams2.json 2>/dev/null || exit 1
+# N = 2 ranks rehearsed on this ONE GPU (gloo moves the gathers through the host): checks the launcher and
+# the N > 1 line; two ranks time-slice the device, so the rate is NOT a scaling number
+TETRIS_BENCH_BACKEND=gloo timeout -k 10 200 python3 bench.py --gpus 2 --batch 524288 --steps 200 --warmup 50 > $OUT/bench_n2_one_gpu_rehearsal_gloo.json 2>/dev/null || exit 1
 echo "bench done"
 
 # 2. kernel trace of the same bench command (per-kernel average duration)
@@ -30,7 +32,10 @@ echo "trace done"
 timeout -k 10 250 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 tools/pmc_probe.py > $OUT/pmc_fetch.log 2>&1 || exit 1
 timeout -k 10 250 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 tools/pmc_probe.py > $OUT/pmc_write.log 2>&1 || exit 1
 python3 tools/parse_pmc.py $OUT/pmc_fetch $OUT/pmc_write > $OUT/pmc_traffic.json || exit 1
-echo "pmc traffic done"
+# the headline line last: it quotes the traffic just measured (same sources: csrc_hash)
+mkdir -p profiles && cp $OUT/pmc_traffic.json profiles/pmc_traffic.json
+timeout -k 10 300 python3 bench.py > $OUT/bench_n1_10x20.json 2> $OUT/bench_n1_10x20.err || exit 1
+echo "pmc traffic + headline bench done"
 
 # 4. per-wave SQ counters of the step kernel (two passes of 8 counters)
 timeout -k 10 250 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVE_CYCLES --output-format csv -d $OUT/pmc_sq1 -- python3 tools/pmc_probe.py > $OUT/pmc_sq1.log 2>&1 || exit 1
@@ -48,7 +53,10 @@ echo "afterstates done"
 timeout -k 10 300 python3 tools/bench_policy.py > $OUT/policy_kernels_10x20.json 2>/dev/null || exit 1
 timeout -k 10 100 python3 tools/ubench/fill_bw.py > $OUT/ubench_fill_bw.txt 2>/dev/null || exit 1
 if [ -x build_variants/row_store ]; then timeout -k 10 60 ./build_variants/row_store > $OUT/ubench_row_store.txt 2>/dev/null || exit 1; fi
+if [ -x build_variants/step_traffic ]; then timeout -k 10 120 ./build_variants/step_traffic > $OUT/ubench_step_traffic.txt 2>/dev/null || exit 1; fi
+timeout -k 10 100 python3 tools/sweep_batch.py 65536 131072 262144 524288 1048576 2097152 4194304 > $OUT/sweep_batch.txt 2>/dev/null || exit 1
 timeout -k 10 100 python3 tools/launch_overhead.py > $OUT/host_launch_overhead.txt 2>/dev/null || exit 1
 timeout -k 10 100 python3 examples/example_play.py > $OUT/example_play.txt 2>/dev/null || exit 1
+if [ -f build_variants/libtetris_stamps.so ]; then timeout -k 10 100 python3 tools/timeline.py > $OUT/step_kernel_timeline.txt 2>/dev/null || exit 1; fi
 echo "policy + ubench done"
 ls -la $OUT

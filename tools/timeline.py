@@ -63,9 +63,9 @@ for rep in range(3):
     print("---- rep %d: %d workgroups (block %d) on %d CUs (min/median/max per CU %d/%d/%d)" % (
         rep, n_wg, blk, ncu, per_cu.min(), int(np.median(per_cu)), per_cu.max()))
     print("launch span %.2f us (first start -> last end); last start at %.2f us" % (t[:, 3].max(), t[:, 0].max()))
-    for name, d in (("start -> tables + first tile in LDS", t[:, 1] - t[:, 0]),
-                    ("-> last tile of wave 0 computed", t[:, 2] - t[:, 1]),
-                    ("-> last stores issued + drained", t[:, 3] - t[:, 2]), ("whole workgroup", t[:, 3] - t[:, 0])):
+    for name, d in (("start -> loads landed + tables in LDS", t[:, 1] - t[:, 0]),
+                    ("compute", t[:, 2] - t[:, 1]),
+                    ("stores issued + drained", t[:, 3] - t[:, 2]), ("whole workgroup", t[:, 3] - t[:, 0])):
         print("  %-36s mean %.2f  p10 %.2f  p50 %.2f  p90 %.2f  max %.2f us" % (
             name, d.mean(), *np.percentile(d, [10, 50, 90]), d.max()))
     # workgroups in each phase over time (whole chip), 1 us bins
