@@ -57,6 +57,8 @@ def test_desc_init_and_argument_errors(hip_lib):
     cols = (ctypes.c_int32 * 16)()
     n = hip_lib.supported_columns(cols, 16)
     assert list(cols)[:n] == [5, 6, 7, 8, 9, 10]
+    from tetris_amd import build
+    assert list(build._COLUMNS) == list(cols)[:n]  # the per-column translation units of the in-tree build
     assert hip_lib.status_words(1 << 20) == 4 * ((1 << 20) // 64)
 
 

@@ -830,7 +830,13 @@ TET_HD void afterstates_env(const W (&col)[C], uint64_t meta, const SetTable& ta
     const bool v11 = TET_WAVE_ANY((d1 & 7u) > 1), v12 = TET_WAVE_ANY((d1 & 7u) > 2), v13 = TET_WAVE_ANY((d1 & 7u) > 3);
 #pragma unroll
     for (int c = 0; c < C; ++c) {
-#pragma unroll 1
+// both orientations of a column in one straight-line block: the two evaluations are independent, and
+// at the two waves per SIMD this walk runs at (it is bound by latency, not by issue) the extra
+// instruction-level parallelism is worth 4 % on the afterstate matrix and 10 % on the greedy policy
+#ifndef TET_AFTER_UNROLL_OI
+#define TET_AFTER_UNROLL_OI 2
+#endif
+#pragma unroll TET_AFTER_UNROLL_OI
      for (int oi = 0; oi < 2; ++oi) {
       const int k = 2 * L + oi;
       const Orient o = unpack_orient(oi ? d1 : d0);

@@ -729,22 +729,14 @@ inline dim3 grid_for(int64_t B) { return dim3((unsigned)((B + kBlock - 1) / kBlo
 template <typename W>
 inline dim3 step_grid(int64_t B) { return dim3((unsigned)((B + step_block<W>() - 1) / step_block<W>())); }
 
-template <template <typename, int> class Launcher, typename P>
-int dispatch(const TetrisDesc* d, const P& p, hipStream_t s) {
-  switch (d->num_columns) {
-#define X(CC)                                                       \
-  case CC:                                                          \
-    if (d->word_bytes == 4) Launcher<uint32_t, CC>::run(p, s);      \
-    else Launcher<uint64_t, CC>::run(p, s);                         \
-    break;
-    TET_COLUMNS(X)
-#undef X
-    default:
-      return TETRIS_E_COLUMNS;
-  }
-  return (int)hipGetLastError();
-}
-
+// ---- translation units ------------------------------------------------------------------------
+// The kernels are templates on the column count, and one hipcc process compiling all of them takes
+// minutes, so the in-tree build (tetris_amd/build.py) compiles this file once per column count
+// (-DTET_PART=<C>: the kernels of that count behind tetris_part_<C>) plus once as the main unit
+// (-DTET_SPLIT_MAIN: the C-ABI, which reaches the column-specific launches through those entries),
+// in parallel, and links the objects.  Compiled alone with neither macro the file is a complete
+// single-unit library (what the tools' experiment builds do).
+template <template <typename, int> class Launcher> struct LaunchId;
 // Kernel variant of a geometry.  Packed boards (tet::board_packed: stored rows within three
 // quarters of the word) always run the variants with a compile-time chunk count -- NCH = 2 on u32,
 // 4 on u64 -- and those variants read / write the packed planes; everything else is NCH = 0 on
@@ -833,8 +825,71 @@ struct LaunchAfter {
   }
 };
 
+
+template <> struct LaunchId<LaunchStep> { static constexpr int value = 0; };
+template <> struct LaunchId<LaunchStepMany> { static constexpr int value = 1; };
+template <> struct LaunchId<LaunchReset> { static constexpr int value = 2; };
+template <> struct LaunchId<LaunchRefresh> { static constexpr int value = 3; };
+template <> struct LaunchId<LaunchRollouts> { static constexpr int value = 4; };
+template <> struct LaunchId<LaunchGreedy> { static constexpr int value = 5; };
+template <> struct LaunchId<LaunchAfter> { static constexpr int value = 6; };
+
+template <template <typename, int> class Launcher, int CC, typename P>
+inline void launch_words(int word_bytes, const void* p, hipStream_t s) {
+  if (word_bytes == 4) Launcher<uint32_t, CC>::run(*static_cast<const P*>(p), s);
+  else Launcher<uint64_t, CC>::run(*static_cast<const P*>(p), s);
+}
+// every launch of column count CC (instantiates all its kernels)
+template <int CC>
+int launch_part(int which, int word_bytes, const void* p, hipStream_t s) {
+  switch (which) {
+    case 0: launch_words<LaunchStep, CC, StepParams>(word_bytes, p, s); break;
+    case 1: launch_words<LaunchStepMany, CC, StepManyParams>(word_bytes, p, s); break;
+    case 2: launch_words<LaunchReset, CC, ResetParams>(word_bytes, p, s); break;
+    case 3: launch_words<LaunchRefresh, CC, RefreshParams>(word_bytes, p, s); break;
+    case 4: launch_words<LaunchRollouts, CC, RolloutParams>(word_bytes, p, s); break;
+    case 5: launch_words<LaunchGreedy, CC, GreedyParams>(word_bytes, p, s); break;
+    case 6: launch_words<LaunchAfter, CC, AfterParams>(word_bytes, p, s); break;
+    default: return TETRIS_E_DESC;
+  }
+  return (int)hipGetLastError();
+}
+
 }  // namespace
 
+#if defined(TET_PART)
+#define TET_PART_NAME2(c) tetris_part_##c
+#define TET_PART_NAME(c) TET_PART_NAME2(c)
+extern "C" __attribute__((visibility("hidden"))) int TET_PART_NAME(TET_PART)(int which, int word_bytes, const void* p,
+                                                                            hipStream_t s) {
+  return launch_part<TET_PART>(which, word_bytes, p, s);
+}
+#elif defined(TET_SPLIT_MAIN)
+#define X(CC) extern "C" __attribute__((visibility("hidden"))) int tetris_part_##CC(int, int, const void*, hipStream_t);
+TET_COLUMNS(X)
+#undef X
+#endif
+
+namespace {
+
+template <template <typename, int> class Launcher, typename P>
+int dispatch(const TetrisDesc* d, const P& p, hipStream_t s) {
+  switch (d->num_columns) {
+#if defined(TET_SPLIT_MAIN)
+#define X(CC) case CC: return tetris_part_##CC(LaunchId<Launcher>::value, d->word_bytes, &p, s);
+#else
+#define X(CC) case CC: return launch_part<CC>(LaunchId<Launcher>::value, d->word_bytes, &p, s);
+#endif
+    TET_COLUMNS(X)
+#undef X
+    default:
+      return TETRIS_E_COLUMNS;
+  }
+}
+
+}  // namespace
+
+#if !defined(TET_PART)
 // ---- C-ABI ---------------------------------------------------------------------------
 extern "C" {
 
@@ -1178,3 +1233,4 @@ int tetris_hip_encode(const TetrisDesc* desc, const int8_t* cells, void* cols, i
 }
 
 }  // extern "C"
+#endif  // !TET_PART

@@ -103,7 +103,9 @@ inline void build_table(const TetrisDesc* d, SetTable* t) {
 // library, the dispatch switch and the CPU test harness)
 // (5 is the lower bound: with 4 columns a horizontal Straight IS a full row wherever it lands, even in the
 // overflow rows, which the bit-parallel valid mask does not model; 10 the upper one, see valid_mask)
+#ifndef TET_COLUMNS  // (experiment builds narrow this: -D'TET_COLUMNS(X)=X(10)')
 #define TET_COLUMNS(X) X(5) X(6) X(7) X(8) X(9) X(10)
+#endif
 
 inline bool columns_supported(int C) {
   switch (C) {

@@ -10,7 +10,10 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from tetris_amd import VecTetris  # noqa: E402
+from tetris_amd import VecTetris, _lib
+if os.environ.get('TETRIS_VARIANT_LIB'):  # time a variant library instead
+    import ctypes
+    _lib._install_test_backend(_lib._Binding(ctypes.CDLL(os.environ['TETRIS_VARIANT_LIB'])))  # noqa: E402
 
 
 def timeit(fn, reps=5, warm=2):

@@ -24,7 +24,7 @@ TETRIS_BENCH_BACKEND=gloo timeout -k 10 200 python3 bench.py --gpus 2 --batch 52
 echo "bench done"
 
 # 2. kernel trace of the same bench command (per-kernel average duration)
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --no-cpu-baseline --steps 300 --warmup 50 > $OUT/trace.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --no-cpu-baseline --no-extras --steps 300 --warmup 50 > $OUT/trace.log 2>&1 || exit 1
 cp $(ls $OUT/trace/*/*kernel_stats.csv | head -1) $OUT/step_kernel_stats_bench_steps300.csv
 echo "trace done"
 
