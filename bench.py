@@ -376,6 +376,7 @@ def run_rank(args):
             roof["frac_4Mi"] = alg * 4 * B / (extras["kernel_ms_4Mi"] * 1e-3) / 1e9 / HBM_PEAK_GBS
         if "peak_copy_measured" in extras:
             roof["peak_copy_measured"] = extras["peak_copy_measured"]
+            roof["peak_copy_how"] = "torch copy_ of 1 GiB (read + written bytes / time), same run, same device"
             roof["frac_of_copy_peak"] = achieved / extras["peak_copy_measured"]
         out = {
             "metric": "env-steps/sec",
