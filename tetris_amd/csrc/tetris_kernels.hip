@@ -503,36 +503,37 @@ struct AfterParams {
 
 // Feature rows are 32 bytes and the rows of different envs are far apart, so a plain store of one
 // row per lane is 64 separate 16-byte write requests per instruction -- the kernel was bound by
-// the L2 write-request rate (75 M requests per launch), not by bytes.  Lanes therefore pair up
-// through LDS: in two steps the even/odd lane of a pair write the two 16-byte halves of ONE row
-// (first the even lane's row, then the odd lane's), so every request carries a whole 32-byte row.
-// All lanes of the wave must call this together (afterstates_env's emit is wave-uniform).
-struct alignas(16) RowExchange {
-  float4 half[kBlock][2];   // [lane][low / high half of the row]
-  uint32_t at[kBlock];      // destination of the row in float4 units, ~0u = nothing to store
-};
-__device__ __forceinline__ void store_row_paired(RowExchange& x, float* base, bool has, uint32_t at4,
-                                                 const float (&f)[8]) {
-  const unsigned t = threadIdx.x;
-  x.half[t][0] = make_float4(f[0], f[1], f[2], f[3]);
-  x.half[t][1] = make_float4(f[4], f[5], f[6], f[7]);
-  x.at[t] = has ? at4 : ~0u;
-  __builtin_amdgcn_wave_barrier();
+// the L2 write-request rate (75 M requests per launch), not by bytes.  Lanes therefore pair up:
+// in two steps the even/odd lane of a pair write the two 16-byte halves of ONE row (first the even
+// lane's row, then the odd lane's), so every request carries a whole 32-byte row.  The halves
+// change lanes through DPP (quad_perm 1,0,3,2: neighbours swap) -- round 1 sent them through LDS,
+// whose write -> wave barrier -> read round trip sat on the critical path of a kernel that is bound
+// by latency.  All lanes of the wave must call this together (afterstates_env's emit is
+// wave-uniform).
+__device__ __forceinline__ uint32_t swap_neighbour(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);
+}
+__device__ __forceinline__ void store_row_paired(float* base, bool has, uint32_t at4, const float (&f)[8]) {
+  const bool odd = threadIdx.x & 1u;
+  const uint32_t at_mine = has ? at4 : ~0u;
+  const uint32_t at_other = swap_neighbour(at_mine);
+  float r[4];  // the partner's half this lane stores: even lanes get the odd row's low half, odd lanes the even row's high half
 #pragma unroll
-  for (unsigned w = 0; w < 2; ++w) {
-    const unsigned src = (t & ~1u) | w, part = t & 1u;
-    const uint32_t d = x.at[src];
-    const float4 v = x.half[src][part];
-    if (d != ~0u) reinterpret_cast<float4*>(base)[(size_t)d + part] = v;
-  }
-  __builtin_amdgcn_wave_barrier();
+  for (int q = 0; q < 4; ++q)
+    r[q] = __uint_as_float(swap_neighbour(__float_as_uint(odd ? f[q] : f[q + 4])));
+  const uint32_t d_even = odd ? at_other : at_mine, d_odd = odd ? at_mine : at_other;  // rows of the pair's even / odd lane
+  const float4 v_even = odd ? make_float4(r[0], r[1], r[2], r[3]) : make_float4(f[0], f[1], f[2], f[3]);
+  const float4 v_odd = odd ? make_float4(f[4], f[5], f[6], f[7]) : make_float4(r[0], r[1], r[2], r[3]);
+  float4* out = reinterpret_cast<float4*>(base);
+  const uint32_t part = odd ? 1u : 0u;
+  if (d_even != ~0u) out[(size_t)d_even + part] = v_even;
+  if (d_odd != ~0u) out[(size_t)d_odd + part] = v_odd;
 }
 
 template <typename W, int C, int NCH>
 __global__ __launch_bounds__(kBlock, TET_AFTER_WAVES) void afterstates_kernel(const AfterParams p) {
   __shared__ SetTable tab;
   __shared__ __attribute__((aligned(16))) uint8_t hole_lut[tet::kFeatureLutBytes];
-  __shared__ RowExchange xch;
   stage_hole_lut(hole_lut);
   stage_table(tab, p.tab);
   const int64_t i0 = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -565,8 +566,8 @@ __global__ __launch_bounds__(kBlock, TET_AFTER_WAVES) void afterstates_kernel(co
     }
     // the row of a placement follows the reference's enumeration order (tet::row_of_slot)
     if (p.feats_all)
-      store_row_paired(xch, p.feats_all, has, env4 + (uint32_t)tet::row_of_slot<C>(full, sk, sc) * rs4, f);
-    store_row_paired(xch, p.feats, has && ((valid >> tet::mask_bit(sk, sc)) & 1),  // game.py:69
+      store_row_paired(p.feats_all, has, env4 + (uint32_t)tet::row_of_slot<C>(full, sk, sc) * rs4, f);
+    store_row_paired(p.feats, has && ((valid >> tet::mask_bit(sk, sc)) & 1),  // game.py:69
                      env4 + (uint32_t)tet::row_of_slot<C>(valid, sk, sc) * rs4, f);
   });
   if (TET_ABLATE & 64) {
@@ -576,8 +577,8 @@ __global__ __launch_bounds__(kBlock, TET_AFTER_WAVES) void afterstates_kernel(co
   const float zero[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   for (int k = 0; k < p.a_max; ++k) {  // zero the rows past the last placement (wave-uniform loop)
     const bool pad = live && k >= nv, pad_all = live && k >= na;
-    if (__ballot(pad) != 0ull) store_row_paired(xch, p.feats, pad, env4 + (uint32_t)k * rs4, zero);
-    if (p.feats_all && __ballot(pad_all) != 0ull) store_row_paired(xch, p.feats_all, pad_all, env4 + (uint32_t)k * rs4, zero);
+    if (__ballot(pad) != 0ull) store_row_paired(p.feats, pad, env4 + (uint32_t)k * rs4, zero);
+    if (p.feats_all && __ballot(pad_all) != 0ull) store_row_paired(p.feats_all, pad_all, env4 + (uint32_t)k * rs4, zero);
   }
   if (live) {
     p.n_valid[i] = (uint8_t)nv;
