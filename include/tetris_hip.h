@@ -148,7 +148,9 @@ int tetris_hip_reset(const TetrisDesc* desc, void* cols, uint64_t* meta, const u
  *  status       : uint32[tetris_hip_status_words(B)] or NULL: per-wave counters (TETRIS_STATUS_*)
  * An out-of-range action (game.py:83 raises IndexError) leaves that env
  * untouched, writes obs = 0, reward = 0, lines = 0 and counts it in
- * status[TETRIS_STATUS_INVALID].
+ * status[TETRIS_STATUS_INVALID].  Negative actions are out of range here (upstream's
+ * `self.afterstates[action]` is NumPy indexing and accepts -n..-1; the single-env facade
+ * tetris_amd.Tetris emulates that on the host).
  * Replay mode: a step consumes one stream row, two when it ends the episode under
  * auto_reset.  An env whose cursor cannot cover that (cursor + 1, or + 2 with auto_reset,
  * > stream_len) is treated exactly like an out-of-range action: untouched and counted as

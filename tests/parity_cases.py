@@ -669,3 +669,28 @@ def rollouts_pinned_to_reference(device, orc, golden_dir):
             np.testing.assert_array_equal(np.isnan(got), np.isnan(want[:, :env.a_max]))
             np.testing.assert_array_equal(np.nan_to_num(got, nan=9.0), np.nan_to_num(want[:, :env.a_max], nan=9.0))
         assert (want == -1).any() and (want < -1).any()
+
+
+def cfg3_full_size_bit_exact(device, orc, B=1 << 20, steps=48):
+    """BASELINE config 3 at its full size -- 1,048,576 envs, 10x20 -- in lock-step with the oracle: every
+    output of every step bit-exact, boards compared every 12 steps (a 252 MB decode each)."""
+    from tetris_amd import VecTetris
+    env = VecTetris(10, 20, B, device=device, auto_reset=True, seed=0)
+    ref = orc.OracleVecEnv(10, 20, B, auto_reset=True, seed=0, nthreads=0)
+    episodes = 0
+    for t in range(steps):
+        obs, rew, done, lines = env.step()  # policy in the kernel, as bench.py runs it
+        o_obs, o_rew, o_done, o_lines, n_bad = ref.step()
+        assert n_bad == 0
+        np.testing.assert_array_equal(env.action.cpu().numpy(), ref.action)
+        np.testing.assert_array_equal(obs.cpu().numpy(), o_obs, err_msg="obs t=%d" % t)
+        np.testing.assert_array_equal(rew.cpu().numpy(), o_rew)
+        np.testing.assert_array_equal(done.cpu().numpy(), o_done.astype(bool))
+        np.testing.assert_array_equal(lines.cpu().numpy(), o_lines)
+        np.testing.assert_array_equal(env.n_valid.cpu().numpy(), ref.n_valid)
+        np.testing.assert_array_equal(env.piece.cpu().numpy(), ref.piece)
+        if t % 12 == 11:
+            np.testing.assert_array_equal(env.boards().cpu().numpy(), ref.cells)
+        episodes += int(o_done.sum())
+    st = env.stats()
+    assert st["invalid"] == 0 and st["episodes"] == episodes and st["steps"] == steps * B and episodes > 1000

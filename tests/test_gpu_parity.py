@@ -152,3 +152,8 @@ def test_facade_rollout_script_and_render(golden_dir):
     import facade_cases as fc
     fc.rollout_script(DEV, golden_dir)
     fc.render_strings(DEV, golden_dir)
+
+
+def test_cfg3_full_size_bit_exact(orc):
+    """BASELINE config 3 (1,048,576 envs): every output of every step against the oracle."""
+    pc.cfg3_full_size_bit_exact(DEV, orc)

@@ -95,3 +95,7 @@ def test_device_bag_properties(host_backend):
 
 def test_rollouts_pinned_to_reference(host_backend, orc, golden_dir):
     pc.rollouts_pinned_to_reference(DEV, orc, golden_dir)
+
+
+def test_cfg3_lockstep_small(host_backend, orc):
+    pc.cfg3_full_size_bit_exact(DEV, orc, B=6000, steps=60)
