@@ -243,6 +243,18 @@ int tetris_hip_rollouts(const TetrisDesc* desc, const void* cols, const uint64_t
                         const float* weights, uint64_t seed, uint64_t step_idx,
                         int64_t env_offset, int64_t B, void* hip_stream);
 
+/*
+ * The reference's TetrominoSampler on NumPy's legacy global stream, on the device (tetromino.py:12-22
+ * over np.random.seed / np.random.permutation): stream[t][i] (uint8 [L][B], the layout of the replay
+ * `stream` of tetris_hip_reset / tetris_hip_step) = the list index the sampler of a reference game
+ * constructed right after np.random.seed(seeds[i]) returns at its t-th call (call 0 = the draw of
+ * Tetris.__init__'s reset, then one per step and one per reset).  seeds: uint32[B] on the device.
+ * With it, B envs replay B independently seeded reference games piece for piece; large batches
+ * use the counter-based bag instead (stream = NULL).
+ */
+int tetris_hip_numpy_bag_stream(const uint32_t* seeds, int32_t n_pieces, int64_t L, uint8_t* stream,
+                                int64_t B, void* hip_stream);
+
 /* uniform random valid action per env: floor(u * n_valid), u from the
  * counter-based hash (the probe policy of SURVEY section 6 / example_play) */
 int tetris_hip_policy_random(const uint8_t* n_valid, int32_t* action, uint64_t seed,

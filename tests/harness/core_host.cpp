@@ -497,6 +497,57 @@ int tetris_host_n_placements(int32_t catalogue_id, int32_t num_columns) {
   return tet::n_placements(catalogue_id, num_columns);
 }
 
+int tetris_host_numpy_bag_stream(const uint32_t* seeds, int32_t n_pieces, int64_t L, uint8_t* stream, int64_t B,
+                                 void* unused) {
+  (void)unused;
+  if (!seeds || !stream) return TETRIS_E_NULL;
+  for (int64_t i = 0; i < B; ++i) {  // same algorithm as numpy_bag_stream_kernel (tetris_kernels.hip)
+    uint32_t mt[624];
+    mt[0] = seeds[i];
+    for (int k = 1; k < 624; ++k) mt[k] = 1812433253U * (mt[k - 1] ^ (mt[k - 1] >> 30)) + (uint32_t)k;
+    int pos = 624;
+    auto next_u32 = [&]() -> uint32_t {
+      if (pos >= 624) {
+        for (int k = 0; k < 624; ++k) {
+          const uint32_t y = (mt[k] & 0x80000000U) | (mt[(k + 1) % 624] & 0x7fffffffU);
+          mt[k] = mt[(k + 397) % 624] ^ (y >> 1) ^ ((y & 1U) ? 0x9908b0dfU : 0U);
+        }
+        pos = 0;
+      }
+      uint32_t y = mt[pos++];
+      y ^= y >> 11;
+      y ^= (y << 7) & 0x9d2c5680U;
+      y ^= (y << 15) & 0xefc60000U;
+      y ^= y >> 18;
+      return y;
+    };
+    uint8_t bag[TETRIS_MAX_PIECES];
+    int left = 0;
+    for (int64_t t = 0; t < L; ++t) {
+      if (left == 0) {
+        for (int k = 0; k < n_pieces; ++k) bag[k] = (uint8_t)k;
+        for (int k = n_pieces - 1; k >= 1; --k) {
+          uint32_t mask = (uint32_t)k;
+          mask |= mask >> 1;
+          mask |= mask >> 2;
+          mask |= mask >> 4;
+          uint32_t v;
+          do {
+            v = next_u32() & mask;
+          } while (v > (uint32_t)k);
+          const uint8_t tmp = bag[k];
+          bag[k] = bag[v];
+          bag[v] = tmp;
+        }
+        left = n_pieces;
+      }
+      stream[t * B + i] = bag[n_pieces - left];
+      --left;
+    }
+  }
+  return 0;
+}
+
 int tetris_host_decode(const TetrisDesc* desc, const void* cols, int8_t* cells, int32_t* heights, int64_t B,
                        void* unused) {
   (void)unused;

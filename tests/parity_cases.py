@@ -694,3 +694,38 @@ def cfg3_full_size_bit_exact(device, orc, B=1 << 20, steps=48):
         episodes += int(o_done.sum())
     st = env.stats()
     assert st["invalid"] == 0 and st["episodes"] == episodes and st["steps"] == steps * B and episodes > 1000
+
+
+def numpy_exact_bag_stream(device, orc, golden_dir):
+    """tetris_hip_numpy_bag_stream = the reference's TetrominoSampler on NumPy's legacy MT19937 stream
+    (tetromino.py:12-22): (a) against the bags np.random.permutation produced in the reference's
+    process for seeds 0..15 (g3), (b) with a batch of envs seeded 0..5 replaying the recorded g2
+    games piece for piece, with no host-side stream."""
+    from tetris_amd import VecTetris
+    g = np.load(os.path.join(golden_dir, "g3_rng.npz"))
+    for n in (2, 7, 9):
+        bags = g["bags_n%d" % n]                       # [16 seeds, 64 bags, n]
+        want = bags.reshape(16, -1).T.astype(np.uint8)  # [64 n, 16]: bag after bag, front to back
+        got = VecTetris.numpy_piece_stream(np.arange(16), n, want.shape[0], device).cpu().numpy()
+        np.testing.assert_array_equal(got, want)
+    # large seeds (32-bit) and a long stream (several MT19937 twists) against the oracle's restatement
+    seeds = np.array([0, 1, 2**31 - 1, 2**32 - 1, 123456789], np.uint64)
+    got = VecTetris.numpy_piece_stream(seeds, 7, 3000, device).cpu().numpy()
+    for k, s in enumerate(seeds):
+        bag = orc.BagSampler(orc.NumpyLegacyRNG(int(s)), 7)
+        np.testing.assert_array_equal(got[:, k], [bag.next() for _ in range(3000)])
+    # whole games: six seeded reference runs as one batch
+    for tag, R in (("default", 20), ("standard7", 40)):
+        gg = np.load(os.path.join(golden_dir, "g2_traj_%s_10x%d.npz" % (tag, R)))
+        pieces = "default" if tag == "default" else STANDARD7
+        T = len(gg["s0_action"])
+        env = VecTetris(10, R, 6, device=device, pieces=pieces, auto_reset=True, numpy_seeds=list(range(6)),
+                        stream_len=2 * T + 8)
+        for t in range(T):
+            np.testing.assert_array_equal(env.piece.cpu().numpy(), [gg["s%d_piece" % s][t] for s in range(6)])
+            act = np.array([gg["s%d_action" % s][t] for s in range(6)], np.int32)
+            obs, rew, done, lines = env.step(torch.from_numpy(act))
+            for s in range(6):
+                np.testing.assert_array_equal(obs[s].cpu().numpy(), gg["s%d_obs" % s][t])
+                assert int(rew[s]) == gg["s%d_reward" % s][t] and bool(done[s]) == bool(gg["s%d_done" % s][t])
+        env.check()

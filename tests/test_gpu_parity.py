@@ -157,3 +157,7 @@ def test_facade_rollout_script_and_render(golden_dir):
 def test_cfg3_full_size_bit_exact(orc):
     """BASELINE config 3 (1,048,576 envs): every output of every step against the oracle."""
     pc.cfg3_full_size_bit_exact(DEV, orc)
+
+
+def test_numpy_exact_bag_stream(orc, golden_dir):
+    pc.numpy_exact_bag_stream(DEV, orc, golden_dir)

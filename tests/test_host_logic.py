@@ -99,3 +99,7 @@ def test_rollouts_pinned_to_reference(host_backend, orc, golden_dir):
 
 def test_cfg3_lockstep_small(host_backend, orc):
     pc.cfg3_full_size_bit_exact(DEV, orc, B=6000, steps=60)
+
+
+def test_numpy_exact_bag_stream(host_backend, orc, golden_dir):
+    pc.numpy_exact_bag_stream(DEV, orc, golden_dir)

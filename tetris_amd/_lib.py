@@ -56,6 +56,7 @@ SIGNATURES = {
     "tetris_hip_policy_greedy": [_dp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
     "tetris_hip_rollouts": [_dp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _u64, _u64, _i64, _i64, _vp],
     "tetris_hip_policy_random": [_vp, _vp, _u64, _u64, _i64, _i64, _vp],
+    "tetris_hip_numpy_bag_stream": [_vp, _i32, _i64, _vp, _i64, _vp],
     "tetris_hip_decode": [_dp, _vp, _vp, _vp, _i64, _vp],
     "tetris_hip_encode": [_dp, _vp, _vp, _i64, _vp],
     "tetris_hip_refresh": [_dp, _vp, _vp, _vp, _i64, _vp],

@@ -696,6 +696,62 @@ __global__ __launch_bounds__(kBlock) void policy_random_kernel(const uint8_t* __
   action[i] = tet::policy_random(key, (uint32_t)(env_offset + i), n_valid[i]);
 }
 
+// The reference's piece sampler on NumPy's legacy global stream, reproduced on the device
+// (tetromino.py:12-22 on top of np.random.seed / np.random.permutation): env i is
+// seeded like `np.random.seed(seeds[i])` right before `game.Tetris(...)` is constructed, and row t of
+// the stream is the list index its sampler hands out at its t-th call.  MT19937 (Matsumoto &
+// Nishimura) with NumPy's init_genrand seeding; permutation(n) = Fisher-Yates from the top with
+// masked rejection sampling on raw 32-bit outputs.  One lane per env, the 2.5 KB generator state in
+// private memory: this is a set-up kernel for exact replays of seeded reference games (small to
+// moderate B), not a hot path -- the counter-based bag in `meta` is the one for large batches.
+__global__ __launch_bounds__(64) void numpy_bag_stream_kernel(const uint32_t* __restrict__ seeds, int n_pieces,
+                                                             int64_t L, uint8_t* __restrict__ stream, int64_t B) {
+  const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (i >= B) return;
+  uint32_t mt[624];
+  mt[0] = seeds[i];
+  for (int k = 1; k < 624; ++k) mt[k] = 1812433253U * (mt[k - 1] ^ (mt[k - 1] >> 30)) + (uint32_t)k;
+  int pos = 624;
+  auto next_u32 = [&]() -> uint32_t {
+    if (pos >= 624) {
+      for (int k = 0; k < 624; ++k) {
+        const uint32_t y = (mt[k] & 0x80000000U) | (mt[k + 1 < 624 ? k + 1 : 0] & 0x7fffffffU);
+        mt[k] = mt[k + 397 < 624 ? k + 397 : k + 397 - 624] ^ (y >> 1) ^ ((y & 1U) ? 0x9908b0dfU : 0U);
+      }
+      pos = 0;
+    }
+    uint32_t y = mt[pos++];
+    y ^= y >> 11;
+    y ^= (y << 7) & 0x9d2c5680U;
+    y ^= (y << 15) & 0xefc60000U;
+    y ^= y >> 18;
+    return y;
+  };
+  uint8_t bag[TETRIS_MAX_PIECES];
+  int left = 0;
+  for (int64_t t = 0; t < L; ++t) {
+    if (left == 0) {  // tetromino.py:15,18-19: a fresh np.random.permutation(n)
+      for (int k = 0; k < n_pieces; ++k) bag[k] = (uint8_t)k;
+      for (int k = n_pieces - 1; k >= 1; --k) {
+        uint32_t mask = (uint32_t)k;
+        mask |= mask >> 1;
+        mask |= mask >> 2;
+        mask |= mask >> 4;
+        uint32_t v;
+        do {
+          v = next_u32() & mask;
+        } while (v > (uint32_t)k);
+        const uint8_t tmp = bag[k];
+        bag[k] = bag[v];
+        bag[v] = tmp;
+      }
+      left = n_pieces;
+    }
+    stream[t * B + i] = bag[n_pieces - left];  // tetromino.py:20-21: element 0, then delete it
+    --left;
+  }
+}
+
 template <typename W>
 __global__ __launch_bounds__(kBlock) void decode_kernel(const W* __restrict__ cols, int8_t* __restrict__ cells,
                                                         int32_t* __restrict__ heights, int C, int rows, int64_t B,
@@ -1197,6 +1253,16 @@ int tetris_hip_policy_random(const uint8_t* n_valid, int32_t* action, uint64_t s
   const uint32_t key = tet::hash_key(seed, step_idx * 4u + 3u);
   hipLaunchKernelGGL(policy_random_kernel, grid_for(B), dim3(kBlock), 0, (hipStream_t)hip_stream, n_valid,
                      action, key, env_offset, B);
+  return (int)hipGetLastError();
+}
+
+int tetris_hip_numpy_bag_stream(const uint32_t* seeds, int32_t n_pieces, int64_t L, uint8_t* stream, int64_t B,
+                                void* hip_stream) {
+  if (!seeds || !stream) return TETRIS_E_NULL;
+  if (n_pieces < 1 || n_pieces > TETRIS_MAX_PIECES) return TETRIS_E_PIECES;
+  if (B <= 0 || L <= 0) return TETRIS_E_BATCH;
+  hipLaunchKernelGGL(numpy_bag_stream_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, (hipStream_t)hip_stream,
+                     seeds, n_pieces, L, stream, B);
   return (int)hipGetLastError();
 }
 

@@ -32,6 +32,9 @@ class VecTetris:
     seed         seed of the counter-based device bag
     piece_stream optional uint8 [L, B]: replay these list indices instead of the
                  device bag (parity runs against a recorded NumPy stream)
+    numpy_seeds  optional [B] ints: env i draws the pieces of a reference game seeded with
+                 ``np.random.seed(numpy_seeds[i])`` -- the reference's sampler on NumPy's MT19937
+                 stream, generated on the device (``stream_len`` draws per env, replay mode)
     env_offset   global index of env 0 (shards of one logical batch draw the
                  same pieces as the unsharded batch)
     compute_obs  False: step() skips the BCTS observation (obs stays zero); for agents that
@@ -46,7 +49,7 @@ class VecTetris:
 
     def __init__(self, num_columns, num_rows, batch_size, device="cuda", pieces="default", auto_reset=False,
                  seed=0, feature_directions=None, piece_stream=None, env_offset=0, afterstate_layout="env_major",
-                 compute_obs=True):
+                 compute_obs=True, numpy_seeds=None, stream_len=4096):
         self._lib = _lib.load()
         self.device = torch.device(device)
         if self.device.type != self._lib.device_type:
@@ -106,6 +109,10 @@ class VecTetris:
         self._own_views()
         self._stream = None
         self._cursor = None
+        if numpy_seeds is not None:
+            if piece_stream is not None:
+                raise ValueError("give either piece_stream or numpy_seeds")
+            piece_stream = self.numpy_piece_stream(numpy_seeds, len(self.piece_names), stream_len, dev)
         if piece_stream is not None:
             ps = torch.as_tensor(piece_stream, dtype=torch.uint8)
             if ps.dim() != 2 or ps.shape[1] != B:
@@ -119,6 +126,22 @@ class VecTetris:
         self._step_call = None
         self._raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None) if self.device.type == "cuda" else None
         self.reset(init_bag=True)
+
+    @staticmethod
+    def numpy_piece_stream(seeds, n_pieces, length, device="cuda"):
+        """uint8 [length, B]: column i = what the reference's ``TetrominoSampler`` (tetromino.py:12-22)
+        returns call after call in a process seeded ``np.random.seed(seeds[i])``, computed on the device
+        (``tetris_hip_numpy_bag_stream``: MT19937 + NumPy's legacy permutation)."""
+        lib = _lib.load()
+        device = torch.device(device)
+        seeds32 = torch.from_numpy(np.asarray(seeds, dtype=np.uint32).view(np.int32).copy()).to(device)
+        out = torch.empty((int(length), seeds32.numel()), dtype=torch.uint8, device=device)
+        stream = None
+        if device.type == "cuda":
+            stream = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+        lib.check(lib.numpy_bag_stream(_ptr(seeds32), int(n_pieces), int(length), _ptr(out), seeds32.numel(), stream),
+                  "tetris_hip_numpy_bag_stream")
+        return out
 
     # -- plumbing -----------------------------------------------------------------
     def _own_views(self):
