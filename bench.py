@@ -155,13 +155,33 @@ def launch_ranks(args):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out.decode())
+    # collect rank 0's stdout while watching every rank: if one dies, the others would sit in the
+    # rendezvous or a collective until its timeout, so they are ended at once
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    rcs = [None] * n
+    failed = False
+    while any(rc is None for rc in rcs):
+        for r, pr in enumerate(procs):
+            if rcs[r] is None:
+                rcs[r] = pr.poll()
+                if rcs[r] not in (None, 0):
+                    failed = True
+        if failed:
+            for r, pr in enumerate(procs):
+                if rcs[r] is None:
+                    pr.kill()
+                    rcs[r] = pr.wait()
+            break
+        time.sleep(0.05)
+    reader.join(timeout=10)
+    sys.stdout.write(b"".join(chunks).decode())
     sys.stdout.flush()
     bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
     if bad:
-        sys.stderr.write("bench.py: rank(s) failed: %s\n" % ", ".join("rank %d rc %d" % b for b in bad))
+        sys.stderr.write("bench.py: rank(s) failed: %s\n" % ", ".join("rank %d rc %s" % b for b in bad))
         return 1
     return 0
 
