@@ -137,6 +137,10 @@ def parse_args(argv=None):
                     help="hold the batch of one GPU as this many env shards, each stepped on its own HIP stream "
                          "(as the shards of several GPUs are): the tail of one shard's launch overlaps the ramp of "
                          "the next.  1 = one launch over the whole batch per step (headline)")
+    ap.add_argument("--graph", type=int, default=1,
+                    help="capture this many steps in one HIP graph (VecTetris.capture_steps) and replay it: still "
+                         "one kernel launch per step on the device, one graph launch per G steps on the host; for "
+                         "small batches where the host enqueue is as long as the kernel (not combined with --fuse)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args(argv)
 
@@ -260,12 +264,20 @@ def run_rank(args):
         return env.done if S == 1 else torch.cat([e.done for e in envs])
 
     fuse = max(1, args.fuse)
+    graph_steps = max(1, args.graph)
+    if graph_steps > 1:
+        if fuse > 1 or S > 1:
+            raise SystemExit("--graph is not combined with --fuse / --streams")
+        fuse = graph_steps  # (host-side bookkeeping below: `fuse` steps per call of shard_step)
     if args.steps % fuse or args.warmup % fuse:
-        raise SystemExit("--steps and --warmup must be multiples of --fuse")
+        raise SystemExit("--steps and --warmup must be multiples of --fuse / --graph")
     traj = [None] * S
+    graphs = [e.capture_steps(graph_steps) for e in envs] if graph_steps > 1 else None
 
     def shard_step(k):
-        if fuse == 1:
+        if graphs is not None:
+            graphs[k].replay()
+        elif fuse == 1:
             envs[k].step()  # action = None: uniform random valid action drawn inside the step kernel
         else:  # `fuse` steps per launch, trajectory buffers reused
             traj[k] = envs[k].step_many(fuse, out=traj[k])
@@ -379,7 +391,9 @@ def run_rank(args):
         traffic = None if (args.no_obs or fuse > 1 or S > 1) else load_traffic(args.columns, args.rows, args.pieces, B)
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "kernel": "step_kernel" if fuse == 1 else "step_many_kernel (%d steps per launch)" % fuse,
+                "kernel": "step_kernel" if fuse == 1 else (
+                    "step_kernel (HIP graph of %d launches)" % fuse if graph_steps > 1
+                    else "step_many_kernel (%d steps per launch)" % fuse),
                 "kernel_ms": k_ms, "algorithmic_bytes_per_env_step": alg,
                 "survey_bytes_per_env_step": alg_survey,
                 "achieved_survey_bytes": alg_survey * B * fuse / (k_ms * 1e-3) / 1e9,
@@ -414,7 +428,8 @@ def run_rank(args):
             "config": {"workload": "%d envs/GPU x %d GPU, %dx%d board, pieces=%s, uniform random valid actions, "
                                    "in-kernel auto-reset, device bag seed 0" % (B, world, args.columns, args.rows,
                                                                                 args.pieces),
-                       "envs_per_gpu": B, "observation_output": not args.no_obs, "env_steps_per_launch": fuse,
+                       "envs_per_gpu": B, "observation_output": not args.no_obs,
+                       "env_steps_per_launch": 1 if graph_steps > 1 else fuse, "steps_per_graph_replay": graph_steps,
                        "streams_per_gpu": S, "board": "%dx%d" % (args.columns, args.rows), "pieces": args.pieces,
                        "backend": ("harness-cpu/" if harness else "") + (backend if world > 1 else "single"),
                        "sharding": "env-index ranges, no data-path collective; RCCL gathers done counters every "

@@ -184,6 +184,18 @@ int tetris_hip_step_call_init(void* call, const TetrisDesc* desc, void* cols, ui
 int tetris_hip_step_call_run(void* call, const int32_t* action, uint64_t step_idx, void* hip_stream);
 
 /*
+ * The bound step with its step index in DEVICE memory, for HIP graphs: the arguments of a captured
+ * kernel launch are frozen at capture time, but every step needs fresh hash keys (piece draw,
+ * built-in policy).  `step_counter` points to one uint64 on the device; this launch plays step
+ * *step_counter + step_rel.  A graph of K steps captures K of these with step_rel = 0 .. K-1
+ * followed by tetris_hip_counter_add(step_counter, K), so that every replay continues where the
+ * last one stopped -- bit-identical to tetris_hip_step with the same indices.
+ */
+int tetris_hip_step_call_run_counted(void* call, const int32_t* action, const uint64_t* step_counter,
+                                     uint32_t step_rel, void* hip_stream);
+int tetris_hip_counter_add(uint64_t* counter, uint64_t n, void* hip_stream);
+
+/*
  * K consecutive Tetris.step calls of every env in ONE launch, for policies that live in the
  * kernel (policy 0: uniform random valid action; 1: greedy on `weights`, HOST pointer to 8
  * floats).  Boards and meta stay in registers between the steps; every step's outputs go to

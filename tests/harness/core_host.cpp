@@ -289,6 +289,16 @@ int tetris_host_step_call_run(void* call_, const int32_t* action, uint64_t step_
                           c.seed, step_idx, c.env_offset, c.B, unused);
 }
 
+int tetris_host_step_call_run_counted(void* call_, const int32_t* action, const uint64_t* step_counter, uint32_t step_rel,
+                                      void* unused) {
+  return tetris_host_step_call_run(call_, action, *step_counter + step_rel, unused);
+}
+int tetris_host_counter_add(uint64_t* counter, uint64_t n, void* unused) {
+  (void)unused;
+  *counter += n;
+  return 0;
+}
+
 int tetris_host_reset(const TetrisDesc* desc, void* cols, uint64_t* meta, const uint8_t* reset_mask,
                       uint8_t* piece_out, uint8_t* n_valid_out, const uint8_t* stream, int32_t* cursor,
                       int64_t stream_len, int32_t init_bag, uint64_t seed, uint64_t step_idx, int64_t env_offset,

@@ -729,3 +729,50 @@ def numpy_exact_bag_stream(device, orc, golden_dir):
                 np.testing.assert_array_equal(obs[s].cpu().numpy(), gg["s%d_obs" % s][t])
                 assert int(rew[s]) == gg["s%d_reward" % s][t] and bool(done[s]) == bool(gg["s%d_done" % s][t])
         env.check()
+
+
+def graph_steps_equal_steps(device, B=5000):
+    """VecTetris.capture_steps(K): replays of the captured graph == the same number of step() calls
+    (built-in policy and an action tensor produced inside the graph), also when plain steps come
+    in between."""
+    from tetris_amd import VecTetris
+    for rows, pieces in ((20, "default"), (40, "standard7")):
+        a = VecTetris(10, rows, B, device=device, pieces=pieces, auto_reset=True, seed=31)
+        b = VecTetris(10, rows, B, device=device, pieces=pieces, auto_reset=True, seed=31)
+        for _ in range(3):
+            a.step()
+            b.step()
+        g = a.capture_steps(6)
+        for rep in range(4):
+            obs, rew, done, lines = g.replay()
+            for k in range(6):
+                b.step()
+            assert torch.equal(a.cols, b.cols) and torch.equal(a.meta, b.meta) and torch.equal(obs, b.obs)
+            assert torch.equal(a.action, b.action) and torch.equal(done, b.done) and a.step_idx == b.step_idx
+            if rep == 1:  # plain steps in between
+                a.step()
+                b.step()
+        assert a.stats() == b.stats()
+        # actions computed inside the graph (here: the policy kernel into a static tensor)
+        a2 = VecTetris(10, rows, B, device=device, pieces=pieces, auto_reset=True, seed=32)
+        b2 = VecTetris(10, rows, B, device=device, pieces=pieces, auto_reset=True, seed=32)
+        act = torch.zeros(B, dtype=torch.int32, device=a2.device)
+
+        def action_fn(env, k):
+            # greedy on feature 3 (landing height) among the valid placements, computed by torch ops
+            f, nv = env.get_after_states()
+            score = f[:, :, 3] + torch.where(torch.arange(env.a_max, device=f.device)[None, :] < nv[:, None].long(), 0.0, 1e9)
+            act.copy_(score.argmin(dim=1).to(torch.int32))
+            return act
+
+        if a2.device.type == "cuda":
+            action_fn(a2, 0)  # warm the allocator outside the capture
+        g2 = a2.capture_steps(3, action_fn=action_fn)
+        for rep in range(3):
+            g2.replay()
+            for k in range(3):
+                f, nv = b2.get_after_states()
+                score = f[:, :, 3] + torch.where(torch.arange(b2.a_max, device=f.device)[None, :] < nv[:, None].long(), 0.0, 1e9)
+                b2.step(score.argmin(dim=1).to(torch.int32))
+            assert torch.equal(a2.cols, b2.cols) and torch.equal(a2.meta, b2.meta) and torch.equal(a2.obs, b2.obs)
+        a2.check()

@@ -161,3 +161,7 @@ def test_cfg3_full_size_bit_exact(orc):
 
 def test_numpy_exact_bag_stream(orc, golden_dir):
     pc.numpy_exact_bag_stream(DEV, orc, golden_dir)
+
+
+def test_graph_steps_equal_steps():
+    pc.graph_steps_equal_steps(DEV)

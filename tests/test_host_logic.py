@@ -103,3 +103,7 @@ def test_cfg3_lockstep_small(host_backend, orc):
 
 def test_numpy_exact_bag_stream(host_backend, orc, golden_dir):
     pc.numpy_exact_bag_stream(DEV, orc, golden_dir)
+
+
+def test_graph_steps_equal_steps(host_backend):
+    pc.graph_steps_equal_steps(DEV, B=300)

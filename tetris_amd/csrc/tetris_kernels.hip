@@ -137,6 +137,12 @@ struct StepParams {
   uint32_t* status;
   uint32_t B;
   uint32_t env_offset;     // global env index of env 0 (mod 2^32)
+  // step index from device memory (HIP-graph replays: the kernel arguments of a captured launch are
+  // frozen, the step's hash keys must not be): when set, the keys are derived in the kernel from
+  // *step_counter + step_rel instead of taken from cfg
+  const uint64_t* step_counter;
+  uint64_t seed;
+  uint32_t step_rel;
   StepCfg cfg;
   SetTable tab;
 };
@@ -257,12 +263,19 @@ __global__ __launch_bounds__(step_block<W>(), (step_waves<W, CR>())) void step_k
     __syncthreads();
   }
   TET_STAMP(1);
-  W* cols = static_cast<W*>(p.cols);
+  StepCfg cfg = p.cfg;
+  if (p.step_counter) {  // wave-uniform: scalar registers
+    const uint64_t c = *p.step_counter;
+    const uint64_t idx = (((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(c >> 32)) << 32) |
+                          __builtin_amdgcn_readfirstlane((uint32_t)c)) + p.step_rel;
+    cfg.key_step = tet::hash_key(p.seed, idx * 4u + 0u);
+    cfg.key_policy = tet::hash_key(p.seed, idx * 4u + 3u);
+  }
   int invalid = 0, done = 0, lines = 0;
   if (live) {
     tet::StepOut out;
     tet::env_step<W, C, NCH, CR>(in.col, in.meta, in.exhausted ? -1 : in.action, p.action == nullptr && !in.exhausted,
-                             tab, hole_lut, &lane_cols[0][threadIdx.x], kBlock, p.cfg, p.env_offset + i, in.draw,
+                             tab, hole_lut, &lane_cols[0][threadIdx.x], kBlock, cfg, p.env_offset + i, in.draw,
                              in.draw_reset, out);
     invalid = out.invalid;
     TET_STAMP(2);
@@ -276,7 +289,7 @@ __global__ __launch_bounds__(step_block<W>(), (step_waves<W, CR>())) void step_k
       st_off(p.meta, i * 8u, in.meta);
       done = out.done;
       lines = out.lines;
-      if (p.stream) p.cursor[i] = in.cursor + 1 + ((out.done && p.cfg.auto_reset) ? 1 : 0);
+      if (p.stream) p.cursor[i] = in.cursor + 1 + ((out.done && cfg.auto_reset) ? 1 : 0);
     }
     st_off(p.reward, i * 4u, (int32_t)out.reward);
     st_off(p.done, i, (uint8_t)out.done);
@@ -687,6 +700,8 @@ __global__ __launch_bounds__(kBlock) void rollouts_kernel(const RolloutParams p)
   }
   p.returns[id] = mean;
 }
+
+__global__ void counter_add_kernel(uint64_t* counter, uint64_t n) { *counter += n; }
 
 __global__ __launch_bounds__(kBlock) void policy_random_kernel(const uint8_t* __restrict__ n_valid,
                                                                int32_t* __restrict__ action, uint32_t key,
@@ -1103,6 +1118,9 @@ static int fill_step_params(StepParams& p, const TetrisDesc* desc, void* cols, u
   p.status = status;
   p.B = (uint32_t)B;
   p.env_offset = (uint32_t)env_offset;
+  p.step_counter = nullptr;
+  p.seed = seed;
+  p.step_rel = 0;
   p.cfg.R = desc->num_rows;
   p.cfg.n_pieces = desc->n_pieces;
   p.cfg.auto_reset = auto_reset;
@@ -1154,6 +1172,25 @@ int tetris_hip_step_call_run(void* call_, const int32_t* action, uint64_t step_i
   p.cfg.key_step = tet::hash_key(call->seed, step_idx * 4u + 0u);
   p.cfg.key_policy = tet::hash_key(call->seed, step_idx * 4u + 3u);
   return dispatch<LaunchStep>(&call->desc, p, (hipStream_t)hip_stream);
+}
+
+int tetris_hip_step_call_run_counted(void* call_, const int32_t* action, const uint64_t* step_counter, uint32_t step_rel,
+                                     void* hip_stream) {
+  TetrisStepCall* call = static_cast<TetrisStepCall*>(call_);
+  if (!call || !step_counter) return TETRIS_E_NULL;
+  if (call->magic != kStepCallMagic) return TETRIS_E_DESC;
+  StepParams p = call->p;  // (a copy: the bound call itself stays usable for plain runs)
+  p.action = action;
+  p.action_out = action ? nullptr : call->action_out;
+  p.step_counter = step_counter;
+  p.step_rel = step_rel;
+  return dispatch<LaunchStep>(&call->desc, p, (hipStream_t)hip_stream);
+}
+
+int tetris_hip_counter_add(uint64_t* counter, uint64_t n, void* hip_stream) {
+  if (!counter) return TETRIS_E_NULL;
+  hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(1), 0, (hipStream_t)hip_stream, counter, n);
+  return (int)hipGetLastError();
 }
 
 int tetris_hip_afterstates(const TetrisDesc* desc, const void* cols, const uint64_t* meta, float* feats,

@@ -239,6 +239,18 @@ class VecTetris:
         self.step_idx += 1
         return self.obs, self.reward, self.done, self.lines
 
+    # -- HIP graph of K steps -------------------------------------------------------------------
+    def capture_steps(self, n_steps, action_fn=None):
+        """Capture ``n_steps`` consecutive steps in ONE HIP graph and return it (``StepGraph``); each
+        ``replay()`` then advances the env by ``n_steps`` steps with a single graph launch.  For small
+        batches, where one step kernel (5-8 us) is about as long as its host enqueue, this takes the
+        host off the critical path.  ``action_fn(env, k)`` (optional) is called at capture time before
+        step k and must enqueue, on the current stream, whatever produces the ``[B]`` int32 action
+        tensor it returns (it is captured too); without it every env plays the built-in uniform
+        random policy.  The step index lives in device memory (``tetris_hip_step_call_run_counted``), so
+        replays are bit-identical to the same number of ``step()`` calls."""
+        return StepGraph(self, int(n_steps), action_fn)
+
     def _bind_step_call(self):
         size = int(self._lib.step_call_size())
         buf = ctypes.create_string_buffer(size + 16)
@@ -464,3 +476,59 @@ class VecTetris:
             self._cursor.copy_(d["cursor"])
         self.step_idx, self.seed = int(d["step_idx"]), int(d["seed"])
         self._step_call = None  # the bound call holds the seed
+
+
+class StepGraph:
+    """``n_steps`` steps of one VecTetris as a HIP graph (``VecTetris.capture_steps``)."""
+
+    def __init__(self, env, n_steps, action_fn=None):
+        if n_steps < 1:
+            raise ValueError("n_steps must be >= 1")
+        self.env, self.n_steps = env, n_steps
+        lib = env._lib
+        self._counter = torch.zeros(1, dtype=torch.int64, device=env.device)
+        self._counter.fill_(env.step_idx)
+        self._expected = env.step_idx
+        call = env._step_call if env._step_call is not None else env._bind_step_call()
+
+        def enqueue():
+            if not env._views_own:
+                env._own_views()
+            for k in range(n_steps):
+                a = None
+                if action_fn is not None:
+                    a = action_fn(env, k)
+                    if a.dtype != torch.int32 or not a.is_contiguous() or a.shape != (env.batch_size,):
+                        raise ValueError("action_fn must return a contiguous int32 [batch_size] tensor")
+                    self._keep.append(a)
+                stream = env._raw_stream(env.device.index) if env._raw_stream is not None else None
+                rc = lib.step_call_run_counted(call, None if a is None else a.data_ptr(), self._counter.data_ptr(), k,
+                                               stream)
+                lib.check(rc, "tetris_hip_step_call_run_counted")
+            stream = env._raw_stream(env.device.index) if env._raw_stream is not None else None
+            lib.check(lib.counter_add(self._counter.data_ptr(), n_steps, stream), "tetris_hip_counter_add")
+
+        self._keep = []
+        self._graph = None
+        self._enqueue = enqueue
+        if env.device.type == "cuda":
+            torch.cuda.synchronize(env.device)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                enqueue()
+            self._graph = g
+
+    def replay(self):
+        """Advance the env by ``n_steps`` steps (returns the per-step views of the last step)."""
+        env = self.env
+        if env.step_idx != self._expected:  # plain step() calls in between: re-seat the device counter
+            self._counter.fill_(env.step_idx)
+        if not env._views_own:
+            env._own_views()
+        if self._graph is not None:
+            self._graph.replay()
+        else:  # no graph support on this device type (CPU test harness): the same launches, eagerly
+            self._enqueue()
+        env.step_idx += self.n_steps
+        self._expected = env.step_idx
+        return env.obs, env.reward, env.done, env.lines
