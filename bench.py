@@ -335,6 +335,8 @@ def run_rank(args):
         return sorted(ms)[len(ms) // 2]
 
     k_ms = kernel_ms_of(lambda: one_step(-2), streams[0])
+    if graph_steps > 1:
+        k_ms /= graph_steps  # one replay = graph_steps launches of the step kernel
     for e in envs:
         e.check()
 
@@ -387,7 +389,8 @@ def run_rank(args):
         alg = algorithmic_bytes_per_env_step(env.n_planes, wb, not args.no_obs)
         alg_survey = survey_bytes_per_env_step(args.columns, wb, not args.no_obs)
         # S shard launches of B/S envs run beside each other during every period k_ms
-        achieved = alg * B * fuse / (k_ms * 1e-3) / 1e9
+        per_launch = 1 if graph_steps > 1 else fuse  # env-steps of every env per timed kernel launch
+        achieved = alg * B * per_launch / (k_ms * 1e-3) / 1e9
         traffic = None if (args.no_obs or fuse > 1 or S > 1) else load_traffic(args.columns, args.rows, args.pieces, B)
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
@@ -396,7 +399,7 @@ def run_rank(args):
                     else "step_many_kernel (%d steps per launch)" % fuse),
                 "kernel_ms": k_ms, "algorithmic_bytes_per_env_step": alg,
                 "survey_bytes_per_env_step": alg_survey,
-                "achieved_survey_bytes": alg_survey * B * fuse / (k_ms * 1e-3) / 1e9,
+                "achieved_survey_bytes": alg_survey * B * per_launch / (k_ms * 1e-3) / 1e9,
                 "peak_spec": HBM_PEAK_GBS,
                 "note": "working set of one launch (~%d MB) fits the 256 MiB Infinity Cache, whose hits FETCH_SIZE / "
                         "WRITE_SIZE count: see frac_4Mi for the same kernel streaming from HBM" % (alg * B // 1000000)}
