@@ -52,6 +52,7 @@ class Tetris:
         self._env = VecTetris(num_columns, num_rows, 1, device=device, pieces=pieces, auto_reset=False,
                               piece_stream=np.zeros((2, 1), np.uint8))
         self._scratch = None
+        self._action_buf = torch.zeros(1, dtype=torch.int32, device=self._env.device)
         self.tetrominos = self._env.tetrominos
         self.tetromino_sampler = TetrominoSampler(self.tetrominos)  # game.py:50 (draws bag #1)
         self._after_token = None
@@ -106,10 +107,16 @@ class Tetris:
     def get_after_states(self, include_terminal=False):
         self._check_feature_type()
         f, nv, fa, na = self._env.get_after_states(include_terminal=True)
-        n_valid, n_all = int(nv[0]), int(na[0])
-        feats = f[0, :n_valid].cpu().numpy()
-        feats_all = fa[0, :n_all].cpu().numpy()
-        mask = int(self._env.meta[0].item()) & ((1 << 48) - 1)
+        # everything the host needs in ONE device -> host copy: both feature matrices, the two counts and
+        # the 48-bit valid mask (as two 24-bit halves: exact in float32)
+        A = self._env.a_max
+        m = self._env.meta[0] & ((1 << 48) - 1)
+        box = torch.cat([f[0].reshape(-1), fa[0].reshape(-1),
+                         torch.stack([nv[0].float(), na[0].float(), (m & 0xFFFFFF).float(), (m >> 24).float()])]).cpu().numpy()
+        n_valid, n_all = int(box[2 * A * 8]), int(box[2 * A * 8 + 1])
+        mask = int(box[2 * A * 8 + 2]) | (int(box[2 * A * 8 + 3]) << 24)
+        feats = box[:A * 8].reshape(A, 8)[:n_valid].copy()
+        feats_all = box[A * 8:2 * A * 8].reshape(A, 8)[:n_all].copy()
         slots = _placements_in_action_order(mask, self.num_columns)
         assert len(slots) == n_valid
         self._after_slots = slots
@@ -147,13 +154,22 @@ class Tetris:
         bonus = (max(bj + nj for bj, nj in zip(b, n)) - 1) / 2.0
         nxt = self.tetromino_sampler.next_tetromino()  # game.py:87
         self._feed_piece(nxt)
-        obs, reward, done, lines = self._env.step(torch.tensor([k], dtype=torch.int32))
-        obs = obs[0].cpu().numpy().copy()
-        reward, done, lines = int(reward[0]), bool(done[0]), int(lines[0])
-        self._env.check()
-        self.current_state = self._decode_state(
-            features=obs, anchor_col=col, anchor_row=int(round(float(obs[3]) - bonus - 1.0)),
-            n_cleared_lines=lines, landing_height_bonus=bonus)
+        env = self._env
+        env.step(self._action_buf.fill_(k))
+        # outputs, the invalid counter and the decoded new state in ONE device -> host copy
+        box = torch.cat([env.obs[0], torch.stack([env.reward[0].float(), env._done[0].float(), env.lines[0].float(),
+                                                  (env.status.view(-1, 4)[:, 0].sum()).float()]),
+                         env.boards()[0].reshape(-1).float(), env.heights()[0].float()]).cpu().numpy()
+        obs = box[:8].astype(np.float32)
+        reward, done, lines = int(box[8]), bool(box[9]), int(box[10])
+        if box[11]:
+            raise IndexError("out-of-range action reached the kernel")  # (cannot happen: checked above)
+        R4, C = self.num_rows + 4, self.num_columns
+        rep = box[12:12 + R4 * C].reshape(R4, C).astype(np.int_)
+        heights = box[12 + R4 * C:12 + R4 * C + C].astype(np.int_)
+        self.current_state = State(rep, lowest_free_rows=heights, features=obs, anchor_col=col,
+                                   anchor_row=int(round(float(obs[3]) - bonus - 1.0)), n_cleared_lines=lines,
+                                   landing_height_bonus=bonus)
         self.current_tetromino = nxt
         self._token += 1
         return self.get_state(), reward, done, lines
