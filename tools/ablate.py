@@ -60,6 +60,7 @@ for rep in range(5):
     for m in masks:
         base.load_state_dict(snap)
         base._lib = libs[m]
+        base._step_call = None  # the bound step call belongs to the library that prepared it
         acts = None
         evs = []
         for t in range(20):
