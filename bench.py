@@ -211,7 +211,10 @@ def run_rank(args):
         dev = torch.device("cuda", dev_index)
         torch.cuda.set_device(dev)
     on_gpu = dev.type == "cuda"
-    if world > 1:
+    # TETRIS_BENCH_FORCE_DIST=1: run the collective path with a world of one rank as well (a 1-GPU box
+    # can then exercise process-group set-up and every RCCL call of the N > 1 path)
+    dist_on = world > 1 or os.environ.get("TETRIS_BENCH_FORCE_DIST") == "1"
+    if dist_on:
         import torch.distributed as dist
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
@@ -243,11 +246,11 @@ def run_rank(args):
             envs.append(VecTetris(args.columns, args.rows, B // S, device=dev, pieces=args.pieces, auto_reset=True,
                                   seed=0, env_offset=rank * B + k * (B // S), compute_obs=not args.no_obs))
     env = envs[0]
-    gather = DoneGather(B)
+    gather = DoneGather(B, force=dist_on)
 
     def barrier():
         sync()
-        if world > 1:
+        if dist_on:
             dist.barrier()
         sync()
 
@@ -291,7 +294,7 @@ def run_rank(args):
             for k in range(S):
                 with on_stream(k):
                     shard_step(k)
-        if world > 1 and t >= 0 and (t + 1) % max(1, args.gather_every // fuse) == 0:
+        if dist_on and t >= 0 and (t + 1) % max(1, args.gather_every // fuse) == 0:
             gather.gather_counters(all_totals())
             n_gathers[0] += 1
 
@@ -302,11 +305,11 @@ def run_rank(args):
     t0 = time.perf_counter()
     for t in range(args.steps // fuse):
         one_step(t)
-    if world > 1:
+    if dist_on:
         gather.gather_bits(all_done())  # the done/reset gather over RCCL
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -344,7 +347,7 @@ def run_rank(args):
     # all-gather + counter all-reduce, host-paired wall time per call
     gather_ms = None
     k_all = [k_ms]
-    if world > 1:
+    if dist_on:
         barrier()
         g0 = time.perf_counter()
         for _ in range(10):
@@ -406,7 +409,7 @@ def run_rank(args):
         if traffic is not None:
             roof["achieved_measured"] = traffic / (k_ms * 1e-3) / 1e9
             roof["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc, csrc_hash %s)" % csrc_hash()
-        if world > 1:
+        if dist_on:
             roof["kernel_ms_per_rank"] = {"min": min(k_all), "max": max(k_all)}
         if "kernel_ms_4Mi" in extras:
             roof["kernel_ms_4Mi"] = extras["kernel_ms_4Mi"]
@@ -434,13 +437,13 @@ def run_rank(args):
                        "envs_per_gpu": B, "observation_output": not args.no_obs,
                        "env_steps_per_launch": 1 if graph_steps > 1 else fuse, "steps_per_graph_replay": graph_steps,
                        "streams_per_gpu": S, "board": "%dx%d" % (args.columns, args.rows), "pieces": args.pieces,
-                       "backend": ("harness-cpu/" if harness else "") + (backend if world > 1 else "single"),
+                       "backend": ("harness-cpu/" if harness else "") + (backend if dist_on else "single"),
                        "sharding": "env-index ranges, no data-path collective; RCCL gathers done counters every "
                                    "%d steps + done bitmask at the end" % args.gather_every},
             "roofline": roof,
             "episodes": totals[1], "lines_cleared": totals[2],
         }
-        if world > 1:
+        if dist_on:
             out["done_gather"] = {"ms_per_gather": gather_ms, "counter_gathers_in_timed_region": n_gathers[0],
                                   "bitmask_gathers_in_timed_region": 1}
         if "tall_10x40" in extras:
@@ -448,7 +451,7 @@ def run_rank(args):
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.columns, args.rows, args.pieces, args.cpu_seconds)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
     return 0
 

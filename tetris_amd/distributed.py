@@ -36,7 +36,8 @@ class DoneGather:
     128 KiB at 1 Mi envs -- latency-bound, kept off the step's critical path by
     calling it every K steps or with async_op)."""
 
-    def __init__(self, local_envs, group=None):
+    def __init__(self, local_envs, group=None, force=False):
+        """force: run the collectives even in a world of one rank (exercises the RCCL calls on a 1-GPU box)."""
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -44,10 +45,11 @@ class DoneGather:
         self._out = None
         # gloo (CPU tests, or rehearsing ranks that share one GPU) moves device tensors through the host
         self._via_cpu = dist.is_initialized() and dist.get_backend(group) == "gloo"
+        self._collective = dist.is_initialized() and (self.world > 1 or force)
 
     def gather_bits(self, done, async_op=False):
         bits = pack_done_bits(done)
-        if self.world == 1:
+        if not self._collective:
             return bits.unsqueeze(0), None
         if self._via_cpu:
             parts = [torch.empty(bits.numel(), dtype=torch.uint8) for _ in range(self.world)]
@@ -67,7 +69,7 @@ class DoneGather:
     def gather_counters(self, totals):
         """Sum of the env's counters (VecTetris.totals(), int64 [4]) over all ranks."""
         s = totals.clone()
-        if self.world > 1:
+        if self._collective:
             if self._via_cpu:
                 c = s.cpu()
                 dist.all_reduce(c, op=dist.ReduceOp.SUM, group=self.group)
