@@ -310,8 +310,9 @@ def run_rank(args):
         one_step(t)
     if dist_on:
         gather.gather_bits(all_done())  # the done/reset gather over RCCL
+    sync()
+    dt = time.perf_counter() - t0   # this rank's K steps + its gathers; the MAX over ranks is taken below
     barrier()
-    dt = time.perf_counter() - t0
     if dist_on:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)

@@ -267,6 +267,11 @@ int tetris_hip_rollouts(const TetrisDesc* desc, const void* cols, const uint64_t
 int tetris_hip_numpy_bag_stream(const uint32_t* seeds, int32_t n_pieces, int64_t L, uint8_t* stream,
                                 int64_t B, void* hip_stream);
 
+/* done flags (uint8[B], as written by tetris_hip_step) -> bitmask, bit i % 8 of byte i / 8: the payload of
+ * the done/reset gather between GPUs (one all-gather of B / 8 bytes per rank).  `bits` must hold
+ * 8 * ceil(B / 64) bytes, 8-byte aligned (whole 64-env words are written). */
+int tetris_hip_pack_done_bits(const uint8_t* done, uint8_t* bits, int64_t B, void* hip_stream);
+
 /* uniform random valid action per env: floor(u * n_valid), u from the
  * counter-based hash (the probe policy of SURVEY section 6 / example_play) */
 int tetris_hip_policy_random(const uint8_t* n_valid, int32_t* action, uint64_t seed,

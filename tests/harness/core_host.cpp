@@ -293,6 +293,13 @@ int tetris_host_step_call_run_counted(void* call_, const int32_t* action, const 
                                       void* unused) {
   return tetris_host_step_call_run(call_, action, *step_counter + step_rel, unused);
 }
+int tetris_host_pack_done_bits(const uint8_t* done, uint8_t* bits, int64_t B, void* unused) {
+  (void)unused;
+  memset(bits, 0, (size_t)((B + 63) / 64) * 8);
+  for (int64_t i = 0; i < B; ++i)
+    if (done[i]) bits[i >> 3] |= (uint8_t)(1u << (i & 7));
+  return 0;
+}
 int tetris_host_counter_add(uint64_t* counter, uint64_t n, void* unused) {
   (void)unused;
   *counter += n;

@@ -780,3 +780,19 @@ def graph_steps_equal_steps(device, B=5000):
                 b2.step(score.argmin(dim=1).to(torch.int32))
             assert torch.equal(a2.cols, b2.cols) and torch.equal(a2.meta, b2.meta) and torch.equal(a2.obs, b2.obs)
         a2.check()
+
+
+def done_bit_packing(device):
+    """tetris_hip_pack_done_bits (one ballot per wavefront) == the torch formulation, odd sizes included."""
+    from tetris_amd import VecTetris, _lib
+    from tetris_amd.distributed import pack_done_bits, unpack_done_bits
+    VecTetris(10, 20, 64, device=device)  # makes sure the library is loaded
+    for n in (1, 63, 64, 65, 1003, 1 << 20):
+        d = torch.rand(n, device=device) < 0.3
+        got = pack_done_bits(d)
+        w = torch.tensor([1, 2, 4, 8, 16, 32, 64, 128], dtype=torch.uint8, device=d.device)
+        pad = (-n) % 8
+        dd = torch.cat([d.to(torch.uint8), d.new_zeros(pad, dtype=torch.uint8)]) if pad else d.to(torch.uint8)
+        want = (dd.view(-1, 8) * w).sum(dim=1).to(torch.uint8)
+        assert torch.equal(got, want), n
+        assert torch.equal(unpack_done_bits(got, n), d)

@@ -165,3 +165,7 @@ def test_numpy_exact_bag_stream(orc, golden_dir):
 
 def test_graph_steps_equal_steps():
     pc.graph_steps_equal_steps(DEV)
+
+
+def test_done_bit_packing():
+    pc.done_bit_packing(DEV)

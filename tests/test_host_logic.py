@@ -107,3 +107,7 @@ def test_numpy_exact_bag_stream(host_backend, orc, golden_dir):
 
 def test_graph_steps_equal_steps(host_backend):
     pc.graph_steps_equal_steps(DEV, B=300)
+
+
+def test_done_bit_packing(host_backend):
+    pc.done_bit_packing(DEV)

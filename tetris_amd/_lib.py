@@ -52,6 +52,7 @@ SIGNATURES = {
     "tetris_hip_step_call_run": [_vp, _vp, _u64, _vp],
     "tetris_hip_step_call_run_counted": [_vp, _vp, _vp, ctypes.c_uint32, _vp],
     "tetris_hip_counter_add": [_vp, _u64, _vp],
+    "tetris_hip_pack_done_bits": [_vp, _vp, _i64, _vp],
     "tetris_hip_step_many": [_dp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _u64, _u64,
                              _i64, _i64, _vp],
     "tetris_hip_afterstates": [_dp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp],

@@ -703,6 +703,15 @@ __global__ __launch_bounds__(kBlock) void rollouts_kernel(const RolloutParams p)
 
 __global__ void counter_add_kernel(uint64_t* counter, uint64_t n) { *counter += n; }
 
+// done flags -> bitmask (bit i % 8 of byte i / 8): one ballot per wavefront, eight bytes per store.
+// The payload of the done/reset gather, the path's only collective.
+__global__ __launch_bounds__(kBlock) void pack_done_bits_kernel(const uint8_t* __restrict__ done,
+                                                                unsigned long long* __restrict__ bits, int64_t B) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const unsigned long long m = __ballot(i < B && done[i] != 0);
+  if ((threadIdx.x & 63) == 0 && (i & ~(int64_t)63) < B) bits[i >> 6] = m;
+}
+
 __global__ __launch_bounds__(kBlock) void policy_random_kernel(const uint8_t* __restrict__ n_valid,
                                                                int32_t* __restrict__ action, uint32_t key,
                                                                int64_t env_offset, int64_t B) {
@@ -1185,6 +1194,14 @@ int tetris_hip_step_call_run_counted(void* call_, const int32_t* action, const u
   p.step_counter = step_counter;
   p.step_rel = step_rel;
   return dispatch<LaunchStep>(&call->desc, p, (hipStream_t)hip_stream);
+}
+
+int tetris_hip_pack_done_bits(const uint8_t* done, uint8_t* bits, int64_t B, void* hip_stream) {
+  if (!done || !bits) return TETRIS_E_NULL;
+  if (B <= 0) return TETRIS_E_BATCH;
+  hipLaunchKernelGGL(pack_done_bits_kernel, grid_for(B), dim3(kBlock), 0, (hipStream_t)hip_stream, done,
+                     reinterpret_cast<unsigned long long*>(bits), B);
+  return (int)hipGetLastError();
 }
 
 int tetris_hip_counter_add(uint64_t* counter, uint64_t n, void* hip_stream) {

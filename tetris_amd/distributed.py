@@ -17,7 +17,22 @@ def shard_range(total_envs, rank, world_size):
 
 
 def pack_done_bits(done):
-    """bool/uint8 [B] -> uint8 [ceil(B/8)] bitmask (bit i%8 of byte i//8)."""
+    """bool/uint8 [B] -> uint8 [ceil(B/8)] bitmask (bit i%8 of byte i//8).  On the device the library packs
+    it with one ballot per wavefront (tetris_hip_pack_done_bits); host tensors go through torch ops."""
+    from . import _lib
+    lib = _lib._BINDING
+    if lib is not None and done.device.type == lib.device_type and hasattr(lib, "pack_done_bits"):
+        import ctypes
+        d = done.view(torch.uint8) if done.dtype == torch.bool else done.to(torch.uint8)
+        d = d.contiguous().flatten()
+        n = d.numel()
+        out = torch.empty(((n + 63) // 64) * 8, dtype=torch.uint8, device=d.device)
+        stream = None
+        if d.device.type == "cuda":
+            stream = ctypes.c_void_p(torch.cuda.current_stream(d.device).cuda_stream)
+        lib.check(lib.pack_done_bits(ctypes.c_void_p(d.data_ptr()), ctypes.c_void_p(out.data_ptr()), n, stream),
+                  "tetris_hip_pack_done_bits")
+        return out[:(n + 7) // 8]
     d = done.to(torch.uint8).flatten()
     pad = (-d.numel()) % 8
     if pad:
