@@ -286,6 +286,33 @@ def run_rank(args):
             traj[k] = envs[k].step_many(fuse, out=traj[k])
 
     n_gathers = [0]
+    # The gathers run on a side stream: it waits for the step just enqueued, reads the flags / counters
+    # (the stepping stream only waits for THAT read), and the collective itself overlaps the following
+    # steps -- the exchange is off the step's critical path, as section 8(e) of the survey describes it.
+    side = torch.cuda.Stream(dev) if (dist_on and on_gpu and backend == "nccl") else None
+
+    def off_path(read, exchange):
+        if side is None:
+            exchange(read())
+            return
+        main = cur_stream()
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            payload = read()
+            read_done = torch.cuda.Event()
+            read_done.record(side)
+            exchange(payload)
+        main.wait_event(read_done)
+        if S > 1:
+            for st in streams:
+                st.wait_event(read_done)
+
+    def gather_counters_now():
+        off_path(all_totals, gather.gather_counters)
+
+    def gather_bits_now():
+        from tetris_amd.distributed import pack_done_bits
+        off_path(lambda: pack_done_bits(all_done()), gather.gather_packed)
 
     def one_step(t):
         if S == 1:
@@ -295,21 +322,24 @@ def run_rank(args):
                 with on_stream(k):
                     shard_step(k)
         if dist_on and t >= 0 and (t + 1) % max(1, args.gather_every // fuse) == 0:
-            gather.gather_counters(all_totals())
+            gather_counters_now()
             n_gathers[0] += 1
 
     for t in range(args.warmup // fuse):
         one_step(t)
     if dist_on:  # every collective of the timed region once before it: RCCL sets up a kind of call at its first use
-        gather.gather_bits(all_done())
-        gather.gather_counters(all_totals())
+        gather_bits_now()
+        gather_counters_now()
     n_gathers[0] = 0
     barrier()
     t0 = time.perf_counter()
-    for t in range(args.steps // fuse):
+    n_calls = args.steps // fuse
+    for t in range(n_calls):
         one_step(t)
-    if dist_on:
-        gather.gather_bits(all_done())  # the done/reset gather over RCCL
+        if dist_on and t == (n_calls - 1) // 2:
+            gather_bits_now()  # the done/reset gather over RCCL (midway: it overlaps the remaining steps)
+    if side is not None:
+        cur_stream().wait_stream(side)
     sync()
     dt = time.perf_counter() - t0   # this rank's K steps + its gathers; the MAX over ranks is taken below
     barrier()

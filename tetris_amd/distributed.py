@@ -63,16 +63,19 @@ class DoneGather:
         self._collective = dist.is_initialized() and (self.world > 1 or force)
 
     def gather_bits(self, done, async_op=False):
-        bits = pack_done_bits(done)
+        return self.gather_packed(pack_done_bits(done), async_op)
+
+    def gather_packed(self, bits, async_op=False):
+        """All-gather of already packed done bitmasks (uint8 [ceil(B/8)] per rank) -> [world, ceil(B/8)]."""
         if not self._collective:
             return bits.unsqueeze(0), None
         if self._via_cpu:
             parts = [torch.empty(bits.numel(), dtype=torch.uint8) for _ in range(self.world)]
             dist.all_gather(parts, bits.cpu(), group=self.group)
             return torch.stack(parts).to(bits.device), None
-        if self._out is None or self._out.device != bits.device:
+        if self._out is None or self._out.device != bits.device or self._out.shape[1] != bits.numel():
             self._out = torch.empty((self.world, bits.numel()), dtype=torch.uint8, device=bits.device)
-        work = dist.all_gather_into_tensor(self._out.view(-1), bits, group=self.group, async_op=async_op)
+        work = dist.all_gather_into_tensor(self._out.view(-1), bits.contiguous(), group=self.group, async_op=async_op)
         return self._out, work
 
     def gather_indices(self, done):
