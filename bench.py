@@ -286,26 +286,23 @@ def run_rank(args):
             traj[k] = envs[k].step_many(fuse, out=traj[k])
 
     n_gathers = [0]
-    # The gathers run on a side stream: it waits for the step just enqueued, reads the flags / counters
-    # (the stepping stream only waits for THAT read), and the collective itself overlaps the following
-    # steps -- the exchange is off the step's critical path, as section 8(e) of the survey describes it.
+    # The gathers: the small read of the flags / counters (a ballot-pack kernel, a column sum) runs in
+    # order on the stepping stream; the collective itself is issued on a side stream that waits for that
+    # read, so it overlaps the following steps and the stepping stream never waits for it -- the
+    # exchange is off the step's critical path, as section 8(e) of the survey describes it.  (Making
+    # the stepping stream wait on the side stream instead costs ~70 us per gather on this stack:
+    # cross-stream dependencies resolve in tens of microseconds, rocprofv3 kernel trace.)
     side = torch.cuda.Stream(dev) if (dist_on and on_gpu and backend == "nccl") else None
 
     def off_path(read, exchange):
+        payload = read()
         if side is None:
-            exchange(read())
-            return
-        main = cur_stream()
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            payload = read()
-            read_done = torch.cuda.Event()
-            read_done.record(side)
             exchange(payload)
-        main.wait_event(read_done)
-        if S > 1:
-            for st in streams:
-                st.wait_event(read_done)
+            return
+        side.wait_stream(cur_stream())
+        payload.record_stream(side)
+        with torch.cuda.stream(side):
+            exchange(payload)
 
     def gather_counters_now():
         off_path(all_totals, gather.gather_counters)
