@@ -145,9 +145,27 @@ def parse_args(argv=None):
     return ap.parse_args(argv)
 
 
+def _load_build_module():
+    """tetris_amd/build.py by path: importing the package would pull in torch, which the parent never does."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_tetris_build", os.path.join(ROOT, "tetris_amd", "build.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
 # ---- parent: start N rank processes (never touches the GPU, never imports torch) ----------------
-def launch_ranks(args):
+def launch_ranks(args, entry=None, prebuild=True, deadline_s=None):
+    """`entry`: the script every rank runs (default: this file; the CPU test wrapper passes itself).
+    The library is built HERE, once, before any rank exists -- N ranks finding no .so would each start
+    their own 7-process hipcc build of the same file."""
     n = args.gpus
+    entry = entry or os.path.abspath(__file__)
+    if prebuild:
+        b = _load_build_module()
+        if not os.path.exists(b.SO_PATH):
+            b.build_hip(force=True)
+    deadline_s = deadline_s or float(os.environ.get("TETRIS_BENCH_DEADLINE_S", "1500"))
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -156,8 +174,12 @@ def launch_ranks(args):
         env = dict(os.environ)
         env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        # RCCL shares device buffers between the ranks of a node through dmabuf IPC handles; this pool's
+        # driver supports no legacy IPC, and without the variable hipIpcGetMemHandle fails.  The image
+        # exports it already (a torchrun launch inherits it the same way); the default only covers a
+        # caller that scrubbed its environment.
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+        procs.append(subprocess.Popen([sys.executable, entry] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
     # collect rank 0's stdout while watching every rank: if one dies, the others would sit in the
     # rendezvous or a collective until its timeout, so they are ended at once
@@ -167,12 +189,16 @@ def launch_ranks(args):
     reader.start()
     rcs = [None] * n
     failed = False
+    t_start = time.monotonic()
     while any(rc is None for rc in rcs):
         for r, pr in enumerate(procs):
             if rcs[r] is None:
                 rcs[r] = pr.poll()
                 if rcs[r] not in (None, 0):
                     failed = True
+        if time.monotonic() - t_start > deadline_s:  # a rank hung in a collective: end the job, do not wait for RCCL's timeout
+            sys.stderr.write("bench.py: ranks still running after %.0f s, ending them\n" % deadline_s)
+            failed = True
         if failed:
             for r, pr in enumerate(procs):
                 if rcs[r] is None:
@@ -191,7 +217,10 @@ def launch_ranks(args):
 
 
 # ---- one rank ------------------------------------------------------------------------------------
-def run_rank(args):
+def run_rank(args, device=None):
+    """`device`: None = cuda:LOCAL_RANK (the product).  tests/bench_cpu_entry.py passes "cpu" after binding
+    the package to the g++ harness build of the lane logic, to exercise this script's host code and the
+    launcher without a GPU; nothing in this file selects a CPU path by itself."""
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -199,13 +228,8 @@ def run_rank(args):
     if "WORLD_SIZE" in os.environ and args.gpus != world:
         raise SystemExit("bench.py: --gpus %d disagrees with WORLD_SIZE=%d" % (args.gpus, world))
     backend = os.environ.get("TETRIS_BENCH_BACKEND", "nccl")  # "gloo": rehearse N ranks on fewer GPUs / on CPU
-    harness = os.environ.get("TETRIS_BENCH_HARNESS") == "1"   # TEST ONLY: CPU harness build of the lane logic
-    if harness:
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        import harness_backend
-        from tetris_amd import _lib
-        _lib._install_test_backend(harness_backend.binding())
-        dev = torch.device("cpu")
+    if device is not None:
+        dev = torch.device(device)
     else:
         dev_index = local_rank % max(1, torch.cuda.device_count()) if world > 1 else 0
         dev = torch.device("cuda", dev_index)
@@ -286,6 +310,7 @@ def run_rank(args):
             traj[k] = envs[k].step_many(fuse, out=traj[k])
 
     n_gathers = [0]
+    n_bit_gathers = [0]
     # The gathers: the small read of the flags / counters (a ballot-pack kernel, a column sum) runs in
     # order on the stepping stream; the collective itself is issued on a side stream that waits for that
     # read, so it overlaps the following steps and the stepping stream never waits for it -- the
@@ -310,6 +335,7 @@ def run_rank(args):
     def gather_bits_now():
         from tetris_amd.distributed import pack_done_bits
         off_path(lambda: pack_done_bits(all_done()), gather.gather_packed)
+        n_bit_gathers[0] += 1
 
     def one_step(t):
         if S == 1:
@@ -328,6 +354,7 @@ def run_rank(args):
         gather_bits_now()
         gather_counters_now()
     n_gathers[0] = 0
+    n_bit_gathers[0] = 0
     barrier()
     t0 = time.perf_counter()
     n_calls = args.steps // fuse
@@ -345,6 +372,22 @@ def run_rank(args):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     totals = gather.gather_counters(all_totals()).cpu().tolist()
+
+    # what the collective layer itself saw: its world size and, per rank, the env range it stepped and the
+    # device it ran on (PCI bus id / uuid where torch exposes them) -- so that "N ranks on N devices" can
+    # be read off the line
+    me = {"rank": rank, "envs": [rank * B, (rank + 1) * B], "device": str(dev), "pid": os.getpid()}
+    if on_gpu:
+        pr = torch.cuda.get_device_properties(dev)
+        me["gpu"] = {"name": pr.name, "pci_bus_id": getattr(pr, "pci_bus_id", None),
+                     "pci_device_id": getattr(pr, "pci_device_id", None), "uuid": str(getattr(pr, "uuid", "")) or None}
+    if dist_on:
+        per_rank = [None] * dist.get_world_size()
+        dist.all_gather_object(per_rank, me)
+        ranks_info = {"world_size_observed": dist.get_world_size(), "backend_observed": dist.get_backend(),
+                      "per_rank": per_rank}
+    else:
+        ranks_info = {"world_size_observed": 1, "backend_observed": None, "per_rank": [me]}
 
     # step-kernel time alone: HIP events on the launch stream (torch's current stream) around runs
     # of back-to-back launches; per-launch time = elapsed / launches (includes the ~1.5 us
@@ -468,15 +511,18 @@ def run_rank(args):
                        "envs_per_gpu": B, "observation_output": not args.no_obs,
                        "env_steps_per_launch": 1 if graph_steps > 1 else fuse, "steps_per_graph_replay": graph_steps,
                        "streams_per_gpu": S, "board": "%dx%d" % (args.columns, args.rows), "pieces": args.pieces,
-                       "backend": ("harness-cpu/" if harness else "") + (backend if dist_on else "single"),
-                       "sharding": "env-index ranges, no data-path collective; RCCL gathers done counters every "
-                                   "%d steps + done bitmask at the end" % args.gather_every},
+                       "backend": backend if dist_on else "single", "device": dev.type,
+                       "sharding": "env-index ranges, no data-path collective; RCCL gathers the done counters every "
+                                   "%d steps and the done bitmask once, midway through the timed region, both on "
+                                   "a side stream" % args.gather_every},
             "roofline": roof,
+            "ranks": ranks_info,
             "episodes": totals[1], "lines_cleared": totals[2],
         }
         if dist_on:
             out["done_gather"] = {"ms_per_gather": gather_ms, "counter_gathers_in_timed_region": n_gathers[0],
-                                  "bitmask_gathers_in_timed_region": 1}
+                                  "bitmask_gathers_in_timed_region": n_bit_gathers[0],
+                                  "note": "cpu_baseline and the extra roofline keys are emitted only at world == 1"}
         if "tall_10x40" in extras:
             out["tall_10x40"] = extras["tall_10x40"]
         if world == 1 and not args.no_cpu_baseline:
@@ -495,13 +541,13 @@ class _Null:
         return False
 
 
-def main():
+def main(device=None, entry=None, prebuild=True):
     args = parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
-        return launch_ranks(args)
-    return run_rank(args)
+        return launch_ranks(args, entry=entry, prebuild=prebuild)
+    return run_rank(args, device=device)
 
 
 if __name__ == "__main__":

@@ -12,9 +12,9 @@ game.py:3-5, tetromino.py:2) and records inputs + expected outputs as small
 
 Fixture families:
   g1_placements_*   every placement of all 9 pieces on random/edge boards
-  g2_traj_*         seeded trajectories through game.Tetris (step outputs,
-                    boards, piece stream incl. bag-across-reset behaviour,
-                    get_after_states matrices)
+  g2_traj_*         seeded trajectories through game.Tetris, seeds 0..31 x 300 steps per
+                    config (step outputs, boards, piece stream incl. bag-across-reset
+                    behaviour; get_after_states matrices for seeds 0 and 1)
   g3_rng            np.random.permutation bags for seeds 0..15
   g4_edges          hand-built edge cases
   g5_dtypes         observation dtypes with / without feature_directions
@@ -503,10 +503,26 @@ def gen_render(game, state, tetromino, utils):
     return out
 
 
+N_TRAJ_SEEDS = 32  # seeds 0..31 x {2-piece, 7-piece} x {10x20, 10x40} x 300 steps
+
+
+def gen_all_trajectories(game, tetromino):
+    for tag, names in (("default", None), ("standard7", STANDARD7)):
+        for R in (20, 40):
+            trajs = {}
+            for seed in range(N_TRAJ_SEEDS):
+                tr = gen_trajectory(game, tetromino, 10, R, names, seed, 300, with_after=(seed < 2))
+                for k, v in tr.items():
+                    trajs[f"s{seed}_{k}"] = v
+            np.savez_compressed(os.path.join(HERE, f"g2_traj_{tag}_10x{R}.npz"), **trajs)
+
+
 def main():
     game, state, tetromino = import_reference()
     only = set(sys.argv[1:])  # e.g. `make_golden.py g7 g8` regenerates just those families
     if only:
+        if "g2" in only:
+            gen_all_trajectories(game, tetromino)
         if "g7" in only:
             np.savez_compressed(os.path.join(HERE, "g7_rollouts.npz"), **gen_rollouts(game, tetromino))
         if "g8" in only:
@@ -519,14 +535,7 @@ def main():
                         **gen_placements(game, state, tetromino, 40, 10, 35, seed=2))
     np.savez_compressed(os.path.join(HERE, "g1_placements_6x10.npz"),
                         **gen_placements(game, state, tetromino, 10, 6, 21, seed=3))
-    for tag, names in (("default", None), ("standard7", STANDARD7)):
-        for R in (20, 40):
-            trajs = {}
-            for seed in range(6):
-                tr = gen_trajectory(game, tetromino, 10, R, names, seed, 300, with_after=(seed < 2))
-                for k, v in tr.items():
-                    trajs[f"s{seed}_{k}"] = v
-            np.savez_compressed(os.path.join(HERE, f"g2_traj_{tag}_10x{R}.npz"), **trajs)
+    gen_all_trajectories(game, tetromino)
     np.savez_compressed(os.path.join(HERE, "g3_rng.npz"), **gen_rng())
     np.savez_compressed(os.path.join(HERE, "g4_edges.npz"), **gen_edges(game, state, tetromino))
     np.savez_compressed(os.path.join(HERE, "g5_dtypes.npz"), **gen_dtypes(game))

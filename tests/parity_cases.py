@@ -86,13 +86,21 @@ def no_auto_reset_and_invalid_actions(device, orc, B=4096):
     assert not cells[dead].any() and (env.n_valid[dead] > 0).all()
 
 
+def n_golden_seeds(g):
+    n = 0
+    while ("s%d_action" % n) in g:
+        n += 1
+    return n
+
+
 def golden_trajectories_replay(device, orc, golden_dir):
     """Recorded game.Tetris runs (live reference, NumPy MT19937 piece stream) replayed
     through the HIP kernels: all seeds of one config form one batch."""
     from tetris_amd import VecTetris
     for tag, R in (("default", 20), ("default", 40), ("standard7", 20), ("standard7", 40)):
         g = np.load(os.path.join(golden_dir, "g2_traj_%s_10x%d.npz" % (tag, R)))
-        seeds = range(6)
+        seeds = range(n_golden_seeds(g))  # all 32 recorded games of the config as ONE batch
+        assert len(seeds) == 32
         T = len(g["s0_action"])
         pieces = "default" if tag == "default" else STANDARD7
         n_pieces = len(pieces) if tag != "default" else 2
@@ -116,9 +124,10 @@ def golden_trajectories_replay(device, orc, golden_dir):
                         np.testing.assert_array_equal(f[i].cpu().numpy(), g["s%d_after_valid" % s][t][:env.a_max])
                         np.testing.assert_array_equal(fa[i].cpu().numpy(), g["s%d_after_all" % s][t][:env.a_max])
             obs, rew, done, lines = env.step(torch.from_numpy(act))
+            obs, rew, done, lines = obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy(), lines.cpu().numpy()
             cols = env.columns().cpu().numpy().astype(np.uint64).T  # [B, C]
             for i, s in enumerate(seeds):
-                np.testing.assert_array_equal(obs[i].cpu().numpy(), g["s%d_obs" % s][t])
+                np.testing.assert_array_equal(obs[i], g["s%d_obs" % s][t])
                 assert int(rew[i]) == g["s%d_reward" % s][t] and bool(done[i]) == bool(g["s%d_done" % s][t])
                 assert int(lines[i]) == g["s%d_lines" % s][t]
                 if not g["s%d_done" % s][t]:
@@ -718,19 +727,21 @@ def numpy_exact_bag_stream(device, orc, golden_dir):
     for k, s in enumerate(seeds):
         bag = orc.BagSampler(orc.NumpyLegacyRNG(int(s)), 7)
         np.testing.assert_array_equal(got[:, k], [bag.next() for _ in range(3000)])
-    # whole games: six seeded reference runs as one batch
+    # whole games: every seeded reference run of a config as one batch
     for tag, R in (("default", 20), ("standard7", 40)):
         gg = np.load(os.path.join(golden_dir, "g2_traj_%s_10x%d.npz" % (tag, R)))
         pieces = "default" if tag == "default" else STANDARD7
         T = len(gg["s0_action"])
-        env = VecTetris(10, R, 6, device=device, pieces=pieces, auto_reset=True, numpy_seeds=list(range(6)),
+        S = n_golden_seeds(gg)
+        env = VecTetris(10, R, S, device=device, pieces=pieces, auto_reset=True, numpy_seeds=list(range(S)),
                         stream_len=2 * T + 8)
         for t in range(T):
-            np.testing.assert_array_equal(env.piece.cpu().numpy(), [gg["s%d_piece" % s][t] for s in range(6)])
-            act = np.array([gg["s%d_action" % s][t] for s in range(6)], np.int32)
+            np.testing.assert_array_equal(env.piece.cpu().numpy(), [gg["s%d_piece" % s][t] for s in range(S)])
+            act = np.array([gg["s%d_action" % s][t] for s in range(S)], np.int32)
             obs, rew, done, lines = env.step(torch.from_numpy(act))
-            for s in range(6):
-                np.testing.assert_array_equal(obs[s].cpu().numpy(), gg["s%d_obs" % s][t])
+            obs, rew, done = obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy()
+            for s in range(S):
+                np.testing.assert_array_equal(obs[s], gg["s%d_obs" % s][t])
                 assert int(rew[s]) == gg["s%d_reward" % s][t] and bool(done[s]) == bool(gg["s%d_done" % s][t])
         env.check()
 

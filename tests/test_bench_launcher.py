@@ -16,10 +16,11 @@ def _run(args, extra_env=None, timeout=280):
     env = dict(os.environ)
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    env.update(TETRIS_BENCH_BACKEND="gloo", TETRIS_BENCH_HARNESS="1")
+    env.update(TETRIS_BENCH_BACKEND="gloo")
     env.update(extra_env or {})
-    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True,
-                          text=True, timeout=timeout)
+    # the CPU entry (tests/bench_cpu_entry.py) binds the harness build and runs bench.main() on CPU tensors
+    return subprocess.run([sys.executable, os.path.join(ROOT, "tests", "bench_cpu_entry.py")] + args, env=env,
+                          capture_output=True, text=True, timeout=timeout)
 
 
 @pytest.mark.timeout(300)
@@ -36,6 +37,32 @@ def test_gpus_2_starts_two_ranks(host_backend):
     assert 0 < k["min"] <= k["max"]
     # whole-job value: both ranks' envs
     assert abs(out["value"] - 2 * 512 * 8 / (out["ms_per_step"] * 8e-3)) < 1e-6 * out["value"]
+    # what the collective layer itself saw: two ranks, two disjoint env ranges
+    assert out["ranks"]["world_size_observed"] == 2
+    assert [r["envs"] for r in out["ranks"]["per_rank"]] == [[0, 512], [512, 1024]]
+    assert out["done_gather"]["bitmask_gathers_in_timed_region"] == 1
+
+
+@pytest.mark.timeout(120)
+def test_failing_rank_ends_the_job(host_backend):
+    """One rank exits non-zero before the rendezvous: the parent must end its sibling (which would
+    otherwise sit in the rendezvous until its timeout) and return 1."""
+    import time
+    t0 = time.time()
+    r = _run(["--gpus", "2", "--steps", "8", "--warmup", "4", "--batch", "512"],
+             extra_env=dict(TETRIS_TEST_FAIL_RANK="1"), timeout=100)
+    assert r.returncode == 1, (r.returncode, r.stderr[-1000:])
+    assert "rank(s) failed" in r.stderr and "rank 1 rc 3" in r.stderr
+    assert time.time() - t0 < 60
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+@pytest.mark.timeout(120)
+def test_parent_deadline(host_backend):
+    """A job that outlives the parent's deadline is ended (rank hung in a collective)."""
+    r = _run(["--gpus", "2", "--steps", "2000000", "--warmup", "0", "--batch", "64", "--gather-every", "1000000"],
+             extra_env=dict(TETRIS_BENCH_DEADLINE_S="8"), timeout=100)
+    assert r.returncode == 1 and "ending them" in r.stderr
 
 
 @pytest.mark.timeout(300)
@@ -43,7 +70,7 @@ def test_single_rank_line_and_mismatch(host_backend):
     r = _run(["--gpus", "1", "--steps", "4", "--warmup", "2", "--batch", "256", "--no-cpu-baseline"])
     assert r.returncode == 0, r.stderr[-2000:]
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
-    assert out["n_gpus"] == 1 and "done_gather" not in out
+    assert out["n_gpus"] == 1 and "done_gather" not in out and out["config"]["device"] == "cpu"
     assert out["roofline"]["algorithmic_bytes_per_env_step"] == 111
     assert out["roofline"]["survey_bytes_per_env_step"] == 127
     assert out["roofline"]["traffic"] is None or out["roofline"]["traffic"] > 0

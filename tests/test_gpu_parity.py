@@ -169,3 +169,38 @@ def test_graph_steps_equal_steps():
 
 def test_done_bit_packing():
     pc.done_bit_packing(DEV)
+
+
+def test_cfg5_full_size_bit_exact(orc):
+    """BASELINE config 5 at its full size -- 1,048,576 envs, 10x40 (u64 boards), in-kernel auto-reset --
+    in lock-step with the oracle: every output of every step."""
+    pc.cfg3_full_size_bit_exact(DEV, orc, R=40, steps=24, board_every=12)
+
+
+def test_bench_rccl_path_one_rank():
+    """bench.py as the driver starts it, but with the collective path forced on in a world of ONE rank
+    (TETRIS_BENCH_FORCE_DIST=1): process-group set-up over RCCL, the barrier, the bitmask all-gather on
+    the side stream, the counter all-reduce and the max-over-ranks reduction all run on this GPU, so the
+    N > 1 code path of BASELINE config 4 is exercised every round even without a multi-GPU node."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.update(TETRIS_BENCH_FORCE_DIST="1", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", LOCAL_WORLD_SIZE="1",
+               MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5",
+                        "--no-extras", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["config"]["backend"] == "nccl" and out["config"]["device"] == "cuda"
+    assert out["ranks"]["world_size_observed"] == 1 and out["ranks"]["backend_observed"] == "nccl"
+    assert out["ranks"]["per_rank"][0]["envs"] == [0, 1 << 20]
+    assert out["done_gather"]["bitmask_gathers_in_timed_region"] == 1 and out["done_gather"]["ms_per_gather"] > 0
+    assert out["episodes"] > 0 and out["n_gpus"] == 1 and out["value"] > 1e9

@@ -94,7 +94,7 @@ def _replay(orc, golden_dir, tag, R, seed):
 def test_g2_trajectories(orc, golden_dir, tag, R):
     """game.py step/reset/is_game_over + bag-across-reset vs recorded runs."""
     total_done = 0
-    for seed in range(6):
+    for seed in range(32):  # SURVEY 8(c): seeds 0..31
         g, p, T, env = _replay(orc, golden_dir, tag, R, seed)
         assert env.piece[0] == int(g[p + "first_piece"])
         for t in range(T):

@@ -60,14 +60,16 @@ class VecTetris:
         self.num_columns, self.num_rows, self.batch_size = int(num_columns), int(num_rows), int(batch_size)
         self.piece_names = resolve_pieces(pieces)
         self.tetrominos = [Tetromino(n, i, self.num_columns) for i, n in enumerate(self.piece_names)]
-        self.auto_reset = bool(auto_reset)
-        self.seed = int(seed)
-        self.env_offset = int(env_offset)
+        self._generation = 0  # bumped whenever something a bound step call / captured graph froze changes
+        self._step_call = None
+        self._auto_reset = bool(auto_reset)
+        self._seed = int(seed)
+        self._env_offset = int(env_offset)
         self.feature_directions = feature_directions
         if afterstate_layout not in ("action_major", "env_major"):
             raise ValueError("afterstate_layout must be 'action_major' or 'env_major'")
         self.afterstate_layout = afterstate_layout
-        self.compute_obs = bool(compute_obs)
+        self._compute_obs = bool(compute_obs)
         self.loss_reward, self.timestep_reward = -100, -1  # game.py:34-35 (baked into the kernel)
 
         ids = (ctypes.c_int32 * len(self.piece_names))(*[CATALOGUE.index(n) for n in self.piece_names])
@@ -123,9 +125,10 @@ class VecTetris:
         self._feats_all = None
         self._n_all = None
         self.step_idx = 0
-        self._step_call = None
         self._raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None) if self.device.type == "cuda" else None
         self.reset(init_bag=True)
+
+    MAX_REPLAY_STREAM_BYTES = 1 << 30  # one byte per (draw, env)
 
     @staticmethod
     def numpy_piece_stream(seeds, n_pieces, length, device="cuda"):
@@ -134,6 +137,13 @@ class VecTetris:
         (``tetris_hip_numpy_bag_stream``: MT19937 + NumPy's legacy permutation)."""
         lib = _lib.load()
         device = torch.device(device)
+        n_bytes = int(length) * int(np.asarray(seeds).size)
+        if n_bytes > VecTetris.MAX_REPLAY_STREAM_BYTES:
+            raise ValueError("a replay stream of %d draws x %d envs is %.1f GiB (limit %.1f GiB): NumPy-exact replay "
+                             "is a set-up mode for moderate batches -- pass a shorter stream_len, or use the "
+                             "counter-based device bag (no numpy_seeds) for large batches"
+                             % (int(length), int(np.asarray(seeds).size), n_bytes / 2.0**30,
+                                VecTetris.MAX_REPLAY_STREAM_BYTES / 2.0**30))
         seeds32 = torch.from_numpy(np.asarray(seeds, dtype=np.uint32).view(np.int32).copy()).to(device)
         out = torch.empty((int(length), seeds32.numel()), dtype=torch.uint8, device=device)
         stream = None
@@ -142,6 +152,28 @@ class VecTetris:
         lib.check(lib.numpy_bag_stream(_ptr(seeds32), int(n_pieces), int(length), _ptr(out), seeds32.numel(), stream),
                   "tetris_hip_numpy_bag_stream")
         return out
+
+    # seed / auto_reset / compute_obs / env_offset are baked into the bound step call (and into every HIP
+    # graph captured from it): assigning one drops the bound call, so that step(), step_many(), reset() and
+    # random_actions() keep agreeing, and invalidates captured graphs (StepGraph.replay raises).
+    def _frozen(name):  # noqa: N805
+        def get(self):
+            return getattr(self, "_" + name)
+
+        def set_(self, value):
+            setattr(self, "_" + name, type(getattr(self, "_" + name))(value))
+            self._invalidate_bound_call()
+        return property(get, set_)
+
+    seed = _frozen("seed")
+    auto_reset = _frozen("auto_reset")
+    compute_obs = _frozen("compute_obs")
+    env_offset = _frozen("env_offset")
+    del _frozen
+
+    def _invalidate_bound_call(self):
+        self._step_call = None
+        self._generation += 1
 
     # -- plumbing -----------------------------------------------------------------
     def _own_views(self):
@@ -458,8 +490,10 @@ class VecTetris:
                 n, " (or the replay piece_stream ran out of rows)" if self._stream is not None else ""))
 
     # -- checkpoint / snapshot --------------------------------------------------------------------
+    STATE_FORMAT = 3  # 1: plane-major cols, C-bit mask fields; 2: tile-major cols, 12-bit mask fields (unversioned)
+
     def state_dict(self):
-        d = dict(cols=self.cols.clone(), meta=self.meta.clone(), n_valid=self.n_valid.clone(),
+        d = dict(format=self.STATE_FORMAT, abi=_lib.ABI_VERSION, cols=self.cols.clone(), meta=self.meta.clone(), n_valid=self.n_valid.clone(),
                  piece=self.piece.clone(), status=self.status.clone(), step_idx=self.step_idx, seed=self.seed,
                  num_columns=self.num_columns, num_rows=self.num_rows, pieces=list(self.piece_names))
         if self._cursor is not None:
@@ -470,12 +504,20 @@ class VecTetris:
         if (d["num_columns"], d["num_rows"], list(d["pieces"])) != (self.num_columns, self.num_rows,
                                                                      list(self.piece_names)):
             raise ValueError("state_dict belongs to a different env configuration")
+        if d.get("format") != self.STATE_FORMAT:
+            raise ValueError("state_dict has storage format %r, this build reads format %d (the layout of `cols` / "
+                             "`meta` changed between them; re-create the env and set_boards() from decoded cells)"
+                             % (d.get("format"), self.STATE_FORMAT))
+        for k in ("cols", "meta", "n_valid", "piece", "status"):
+            if tuple(d[k].shape) != tuple(getattr(self, k).shape) or d[k].dtype != getattr(self, k).dtype:
+                raise ValueError("state_dict[%r] is %s %s, this env holds %s %s (different batch size?)"
+                                 % (k, tuple(d[k].shape), d[k].dtype, tuple(getattr(self, k).shape), getattr(self, k).dtype))
         for k in ("cols", "meta", "n_valid", "piece", "status"):
             getattr(self, k).copy_(d[k])
         if self._cursor is not None and "cursor" in d:
             self._cursor.copy_(d["cursor"])
-        self.step_idx, self.seed = int(d["step_idx"]), int(d["seed"])
-        self._step_call = None  # the bound call holds the seed
+        self.step_idx = int(d["step_idx"])
+        self.seed = int(d["seed"])  # (drops the bound step call and invalidates captured graphs)
 
 
 class StepGraph:
@@ -490,6 +532,13 @@ class StepGraph:
         self._counter.fill_(env.step_idx)
         self._expected = env.step_idx
         call = env._step_call if env._step_call is not None else env._bind_step_call()
+        self._generation = env._generation
+        self._call_buf = env._step_call_buf  # the bound call's memory must outlive every launch enqueued from here
+
+        def launch_stream():  # the stream being captured / the current stream, exactly as step() picks it
+            if env._raw_stream is not None:
+                return env._raw_stream(env.device.index)
+            return env._hip_stream()
 
         def enqueue():
             if not env._views_own:
@@ -501,12 +550,10 @@ class StepGraph:
                     if a.dtype != torch.int32 or not a.is_contiguous() or a.shape != (env.batch_size,):
                         raise ValueError("action_fn must return a contiguous int32 [batch_size] tensor")
                     self._keep.append(a)
-                stream = env._raw_stream(env.device.index) if env._raw_stream is not None else None
                 rc = lib.step_call_run_counted(call, None if a is None else a.data_ptr(), self._counter.data_ptr(), k,
-                                               stream)
+                                               launch_stream())
                 lib.check(rc, "tetris_hip_step_call_run_counted")
-            stream = env._raw_stream(env.device.index) if env._raw_stream is not None else None
-            lib.check(lib.counter_add(self._counter.data_ptr(), n_steps, stream), "tetris_hip_counter_add")
+            lib.check(lib.counter_add(self._counter.data_ptr(), n_steps, launch_stream()), "tetris_hip_counter_add")
 
         self._keep = []
         self._graph = None
@@ -521,6 +568,10 @@ class StepGraph:
     def replay(self):
         """Advance the env by ``n_steps`` steps (returns the per-step views of the last step)."""
         env = self.env
+        if env._generation != self._generation:
+            raise RuntimeError("this StepGraph was captured before the env's seed / auto_reset / compute_obs / "
+                               "env_offset changed (or load_state_dict ran): its launches hold the old values -- "
+                               "capture a new one with env.capture_steps()")
         if env.step_idx != self._expected:  # plain step() calls in between: re-seat the device counter
             self._counter.fill_(env.step_idx)
         if not env._views_own:
