@@ -24,6 +24,14 @@ const FeatureLut kFeatureLutHost = {{
 #include "../../tetris_amd/csrc/tetris_feature_lut.inc"
 }};
 const uint8_t* const kHoleLut = reinterpret_cast<const uint8_t*>(&kFeatureLutHost);
+// tables of the kernels that walk the afterstates (tet::AfterLut)
+struct alignas(16) AfterLutData {
+  uint8_t bytes[tet::kAfterLutBytes];
+};
+const AfterLutData kAfterLutHost = {{
+#include "../../tetris_amd/csrc/tetris_after_lut.inc"
+}};
+const uint8_t* const kAfterLut = reinterpret_cast<const uint8_t*>(&kAfterLutHost);
 
 // boards in memory: the library's own packed / unpacked plane format (tet::board_packed)
 template <typename W, int C>
@@ -188,7 +196,7 @@ void after_impl(const TetrisDesc* desc, const void* cols_, const uint64_t* meta,
     }
     int nv = tet::popc(valid), na = tet::popc(full);
     bool consistent = true;
-    tet::afterstates_env<W, C, 0>(col, meta[i], tab, kHoleLut, R, [&](bool has, int sk, int sc, float (&f)[8]) {
+    tet::afterstates_env<W, C, 0>(col, meta[i], tab, kAfterLut, R, [&](bool has, int sk, int sc, float (&f)[8]) {
           if (!has) return;
       const int s = tet::mask_bit(sk, sc);
       // cross-checks (test harness only): (1) the incremental features against the full
@@ -367,7 +375,7 @@ int tetris_host_policy_greedy(const TetrisDesc* desc, const void* cols_, const u
         for (int k = 0; k < desc->a_max; ++k) fall[k] = 0.f;
       float best = 0.f;
       int best_row = -1;
-      tet::afterstates_env<W, C, 0>(col, meta[i], tab, kHoleLut, desc->num_rows, [&](bool has, int sk, int sc, float (&f)[8]) {
+      tet::afterstates_env<W, C, 0>(col, meta[i], tab, kAfterLut, desc->num_rows, [&](bool has, int sk, int sc, float (&f)[8]) {
           if (!has) return;
         const float v = tet::fitness_of(f, w);
         if (fall) fall[tet::row_of_slot<C>(full, sk, sc)] = v;
@@ -411,7 +419,7 @@ int tetris_host_rollouts(const TetrisDesc* desc, const void* cols_, const uint64
             const uint64_t uid = ((uint64_t)(env_offset + i) * (uint64_t)a_max + (uint64_t)a0) * (uint64_t)n + r;
             const uint32_t key0 = tet::mix32(key ^ ((uint32_t)(uid >> 32) * 0x9E3779B1u));
             W scratch[C];
-            sum += tet::rollout_env<W, C>(col, meta[i], a0, length, policy, w, tab, kHoleLut, scratch, 1,
+            sum += tet::rollout_env<W, C>(col, meta[i], a0, length, policy, w, tab, kAfterLut, scratch, 1,
                                           desc->num_rows, desc->n_pieces, key0, (uint32_t)uid);
           }
           mean = (double)sum / (double)n;
@@ -456,7 +464,7 @@ int tetris_host_step_many(const TetrisDesc* desc, void* cols_, uint64_t* meta, i
           const uint64_t valid = tet::meta_mask(m);
           float best = 0.f;
           int best_row = -1;
-          tet::afterstates_env<W, C, 0>(col, m, tab, kHoleLut, cfg.R, [&](bool has, int sk, int sc, float (&f)[8]) {
+          tet::afterstates_env<W, C, 0>(col, m, tab, kAfterLut, cfg.R, [&](bool has, int sk, int sc, float (&f)[8]) {
           if (!has) return;
             if ((valid >> tet::mask_bit(sk, sc)) & 1) {
               const float v = tet::fitness_of(f, w);
@@ -472,8 +480,12 @@ int tetris_host_step_many(const TetrisDesc* desc, void* cols_, uint64_t* meta, i
         }
         W scratch[C];
         tet::StepOut out;
-        tet::env_step<W, C>(col, m, action, use_policy, tab, kHoleLut, scratch, 1, cfg, (uint32_t)(env_offset + i),
-                            -1, -1, out);
+        if (policy == 1)  // as the kernel: the greedy variant steps on the afterstate tables
+          tet::env_step<W, C, 0, 12, true>(col, m, action, use_policy, tab, kAfterLut, scratch, 1, cfg,
+                                           (uint32_t)(env_offset + i), -1, -1, out);
+        else
+          tet::env_step<W, C>(col, m, action, use_policy, tab, kHoleLut, scratch, 1, cfg, (uint32_t)(env_offset + i),
+                              -1, -1, out);
         const int64_t e = (int64_t)k * B + i;
         if (obs)
           for (int q = 0; q < 8; ++q) obs[e * 8 + q] = out.obs[q];

@@ -5,7 +5,8 @@ import subprocess
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 SO_PATH = os.path.join(_CSRC, "libtetris_hip.so")
-_SOURCES = ["tetris_kernels.hip", "tetris_core.hpp", "tetris_table.hpp", "tetris_feature_lut.inc", "tetris_feature_lut10.inc"]
+_SOURCES = ["tetris_kernels.hip", "tetris_core.hpp", "tetris_table.hpp", "tetris_feature_lut.inc", "tetris_feature_lut10.inc",
+            "tetris_after_lut.inc"]
 _HEADER = os.path.join(os.path.dirname(_CSRC), "..", "include", "tetris_hip.h")
 
 

@@ -24,6 +24,9 @@
 #ifndef TET_ABLATE
 #define TET_ABLATE 0
 #endif
+#ifndef TET_RESCUE_SKIP
+#define TET_RESCUE_SKIP 1   // 0: valid_mask always evaluates the rescue by cleared rows (A/B timing)
+#endif
 
 // wave-uniform "does any active lane want this": lets code that only some pieces need be
 // skipped by the whole wavefront (one env per lane).  On the host build it is the lane itself.
@@ -362,6 +365,19 @@ struct LutLayout {
 };
 constexpr int kFeatureLutBytes = LutLayout<12>::kBytes;
 constexpr int kFeatureLut10Bytes = LutLayout<10>::kBytes;
+// tables of the afterstate kernels (tetris_after_lut.inc): the hole tables for 12-row chunks at the
+// offsets of LutLayout<12>, then ONE 32-bit entry per 12-row chunk of a column's well cells,
+// S | trail << 16 | lead << 24.  The afterstate walk re-evaluates the wells of up to five columns per
+// placement and is bound by the number of LDS reads (one pipe per CU, 3-4-way bank conflicts on
+// random indices), so it fetches the three fields with one read; the stepping kernels are bound by
+// vector instructions and keep the ready-to-use byte tables.
+struct AfterLut {
+  static constexpr int kHoleA = LutLayout<12>::kHoleA, kHoleU = LutLayout<12>::kHoleU;
+  static constexpr int kWellsPack = 2 * LutLayout<12>::kHoleEntries;
+  static constexpr int kSelPair = kWellsPack + 4 * LutLayout<12>::kWellsEntries, kSelNib = kSelPair + 256 * 8;
+  static constexpr int kBytes = kSelNib + 16 * 4;
+};
+constexpr int kAfterLutBytes = AfterLut::kBytes;
 
 // bit c -> bit 2c (c < 16)
 TET_HD uint32_t spread2(uint32_t x) {
@@ -565,8 +581,36 @@ TET_HD int col_wells(W x, W L, W Rr, int hi, int R, bool left_wall, bool right_w
   return (TET_ABLATE & 32) ? 0 : total;
 }
 
+// The same sum through the packed table of the afterstate kernels (AfterLut::kWellsPack: 12-row chunks,
+// entry = S | trail << 16 | lead << 24): one LDS read per chunk.
+template <typename W, int NCH = 0>
+TET_HD int col_wells_packed(W x, W L, W Rr, int hi, int R, bool left_wall, bool right_wall, const uint32_t* pack) {
+  constexpr int CR = 12;
+  W w = (W)(~x & L & Rr);
+  if (left_wall || right_wall) w = (W)(w & lowmask<W>(hi > R ? hi : R));
+  uint32_t total = 0, carry = 0;
+#pragma unroll
+  for (int k = 0; CR * k < (int)(8 * sizeof(W)) - 1; ++k) {
+    if (NCH > 0 ? k < NCH : (k < 2 || CR * k < R + 4)) {
+      const uint32_t up = (uint32_t)(w >> (CR * k));
+      const bool last = NCH > 0 && k == NCH - 1;
+      const uint32_t e = pack[last ? up : (up & 4095u)];
+      total += e & 0xFFFFu;
+      const uint32_t lead = e >> 24, trail = (e >> 16) & 255u;
+      if (k == 0) {
+        if (!last) carry = trail;
+      } else {
+        total += carry * lead;
+        if (!last) carry = (lead == (uint32_t)CR) ? carry + (uint32_t)CR : trail;
+      }
+    }
+  }
+  return (int)total;
+}
+
 // state.py:175-280.  out = f0,f1,f2,f4,f5,f7.
-template <typename W, int C, int NCH = 0, int CR = 12>
+// PACKW: hole_lut is an AfterLut (packed wells entries) instead of a LutLayout<CR>
+template <typename W, int C, int NCH = 0, int CR = 12, bool PACKW = false>
 TET_HD void board_features(const W (&col)[C], const int (&h)[C], int R, const uint8_t* hole_lut,
                            int& rows_with_holes, int& col_trans, int& holes, int& wells, int& row_trans,
                            int& hole_depth) {
@@ -590,7 +634,11 @@ TET_HD void board_features(const W (&col)[C], const int (&h)[C], int R, const ui
     hole_rows |= ho;                              // state.py:215
     f5 += col_rowtrans<W>(col[i], L, h[i], hL, nh_left);
     nh_left = nh;
-    f4 += col_wells<W, NCH, CR>(col[i], L, Rr, h[i], R, i == 0, i == C - 1, hole_lut);
+    if (PACKW)
+      f4 += col_wells_packed<W, NCH>(col[i], L, Rr, h[i], R, i == 0, i == C - 1,
+                                     reinterpret_cast<const uint32_t*>(hole_lut + AfterLut::kWellsPack));
+    else
+      f4 += col_wells<W, NCH, CR>(col[i], L, Rr, h[i], R, i == 0, i == C - 1, hole_lut);
     if (TET_FENCE_EVERY > 0 && i % TET_FENCE_EVERY == TET_FENCE_EVERY - 1 && i + 1 < C) {
       TET_PIN(f1);
       TET_PIN(f2);
@@ -609,11 +657,11 @@ TET_HD void board_features(const W (&col)[C], const int (&h)[C], int R, const ui
 }
 
 // state.py:97-107: the eight BCTS features as float32
-template <typename W, int C, int NCH = 0, int CR = 12>
+template <typename W, int C, int NCH = 0, int CR = 12, bool PACKW = false>
 TET_HD void bcts_features(const W (&col)[C], const int (&h)[C], int R, const uint8_t* hole_lut, int anchor_row,
                           int H, int eroded_cells, int n_cleared, float (&f)[8]) {
   int f0, f1, f2, f4, f5, f7;
-  board_features<W, C, NCH, CR>(col, h, R, hole_lut, f0, f1, f2, f4, f5, f7);
+  board_features<W, C, NCH, CR, PACKW>(col, h, R, hole_lut, f0, f1, f2, f4, f5, f7);
   f[0] = (float)f0;
   f[1] = (float)f1;
   f[2] = (float)f2;
@@ -651,12 +699,8 @@ template <typename W, int C>
 TET_HD uint64_t valid_mask(const W (&col)[C], const int (&h)[C], const OrientEntry* tab, uint64_t fullmask, int R) {
   static_assert(C <= 10, "missing-cell rows are packed 3 bits per column into 32 bits; 10-bit level fields");
   uint32_t P[3] = {0u, 0u, 0u};
-  uint32_t Fall = 0;
 #pragma unroll
-  for (int c = 0; c < C; ++c) {
-    P[c >> 2] |= (uint32_t)h[c] << (8 * (c & 3));
-    Fall |= ((uint32_t)(col[c] >> (R - 3)) & 7u) << (3 * c);  // cells of rows R-3..R-1
-  }
+  for (int c = 0; c < C; ++c) P[c >> 2] |= (uint32_t)h[c] << (8 * (c & 3));
   uint32_t lv[4];
 #pragma unroll
   for (int l = 1; l <= 4; ++l) {
@@ -670,18 +714,31 @@ TET_HD uint64_t valid_mask(const W (&col)[C], const int (&h)[C], const OrientEnt
   }
   const uint64_t Z = ((uint64_t)lv[0] << 10) | ((uint64_t)lv[1] << 20) | ((uint64_t)lv[2] << 30) |
                      ((uint64_t)lv[3] << 40);
-  const uint32_t Mall = ~Fall;  // missing cells, 3 bits per column
-  uint32_t X[3], Y[3];
+  // A placement that pokes above row R - 1 is rescued only by a row among R-3 .. R-1 that the piece
+  // completes, i.e. one that misses at most four cells.  A cell in row R-3 or above means h >= R - 2
+  // (level set 3), so when fewer than C - 4 columns reach that height no such row exists: the whole
+  // rescue evaluation (a third of this function) is skipped -- by the wavefront, when none of its
+  // envs needs it, which is the rule for boards that are not stacked to the top.
+  const bool rescue = !TET_RESCUE_SKIP || TET_WAVE_ANY(popc(lv[2]) >= C - 4);
+  uint32_t X[3] = {0u, 0u, 0u}, Y[3] = {0u, 0u, 0u};
+  uint32_t rv1 = 0, rv2 = 0;
+  if (rescue) {
+    uint32_t Fall = 0;
 #pragma unroll
-  for (int t = 0; t < 3; ++t) {
-    const uint32_t m = (Mall >> t) & (0x09249249u & ((1u << (3 * C)) - 1u));  // bit 3c: column c misses row R-3+t
-    const int lo = (__builtin_ctz(m | 0x80000000u) * 11) >> 5;                // / 3
-    const int hi = ((31 - __builtin_clz(m | 1u)) * 11) >> 5;
-    X[t] = ~0u << hi;
-    Y[t] = m ? (2u << lo) - 1u : 0u;  // a full row (only on boards that were set from outside) rescues nothing
+    for (int c = 0; c < C; ++c) Fall |= ((uint32_t)(col[c] >> (R - 3)) & 7u) << (3 * c);  // cells of rows R-3..R-1
+    const uint32_t Mall = ~Fall;  // missing cells, 3 bits per column
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const uint32_t m = (Mall >> t) & (0x09249249u & ((1u << (3 * C)) - 1u));  // bit 3c: column c misses row R-3+t
+      const int lo = (__builtin_ctz(m | 0x80000000u) * 11) >> 5;                // / 3
+      const int hi = ((31 - __builtin_clz(m | 1u)) * 11) >> 5;
+      X[t] = ~0u << hi;
+      Y[t] = m ? (2u << lo) - 1u : 0u;  // a full row (only on boards that were set from outside) rescues nothing
+    }
+    const uint32_t s0 = X[0] & Y[0], s1 = X[1] & Y[1], s2 = X[2] & Y[2];
+    rv1 = s0 | s1 | s2;  // vertical Straight: any of its three lower rows
+    rv2 = s1 & s2;       //                    / both of R-2, R-1
   }
-  const uint32_t s0 = X[0] & Y[0], s1 = X[1] & Y[1], s2 = X[2] & Y[2];
-  const uint32_t rv1 = s0 | s1 | s2, rv2 = s1 & s2;  // vertical Straight: any of its three lower rows / both of R-2, R-1
   const uint32_t cm = (1u << C) - 1u;
   uint64_t mask = 0;
 #pragma unroll
@@ -691,12 +748,15 @@ TET_HD uint64_t valid_mask(const W (&col)[C], const int (&h)[C], const OrientEnt
 #pragma unroll
     for (int j = 0; j < 4; ++j) r |= (uint32_t)(Z >> e.sh[j]);
     const uint32_t i1 = r >> 10, i2 = r;
-    // rescue by one cleared row (e = 1)
-    uint32_t r1 = ((X[1] >> e.rj1[0]) & (Y[1] >> e.rj0[0])) | ((X[2] >> e.rj1[1]) & (Y[2] >> e.rj0[1]));
-    r1 = (rv1 & e.vert4) | (r1 & ~e.vert4);
-    const uint32_t r2 = rv2 & e.vert4;
-    const uint32_t v = (~i1 | (~(i2 & ~r2) & r1)) & cm;
-    mask |= (uint64_t)v << (kFieldStride * k);
+    uint32_t v = ~i1;
+    if (rescue) {
+      // rescue by one cleared row (e = 1)
+      uint32_t r1 = ((X[1] >> e.rj1[0]) & (Y[1] >> e.rj0[0])) | ((X[2] >> e.rj1[1]) & (Y[2] >> e.rj0[1]));
+      r1 = (rv1 & e.vert4) | (r1 & ~e.vert4);
+      const uint32_t r2 = rv2 & e.vert4;
+      v |= ~(i2 & ~r2) & r1;
+    }
+    mask |= (uint64_t)(v & cm) << (kFieldStride * k);
   }
   return mask & fullmask;
 }
@@ -776,26 +836,45 @@ TET_HD int stamp_scratch(W (&col)[C], W* scratch, int sstride, int c, uint32_t d
 // with the BCTS features of its afterstate.  On the device the calls are WAVE-UNIFORM: every lane
 // of the wavefront reaches every call (so the caller may cooperate across lanes, e.g. to merge
 // stores) and `has` tells whether this lane's env really has the placement (f is garbage
-// otherwise).  The per-column feature terms of the current board are computed once; a placement
-// that clears no line changes at most its footprint columns, so only those (plus the wells of the
-// left neighbour and the row transitions / wells of the right one) are re-evaluated -- with the
-// left column c static, all of that indexes registers statically.  Placements that do clear lines
-// (rare) take the full path.
+// otherwise).  Slots are walked in the reference's enumeration order (loop L, column c,
+// orientation o) so that consecutive calls of emit produce consecutive feature rows.
+//
+// The per-column terms of the current board are computed once (chunk tables); a placement that
+// clears no line changes the board in at most four adjacent columns, and its features are those
+// sums plus differences:
+//  * footprint column j (piece cells in rows a+b_j .. a+b_j+n_j-1 above a column of height h_j): the
+//    g_j = a + b_j - h_j cells left empty under the piece are new holes -- one more hole run if
+//    g_j > 0 -- and the n_j new cells lie above every hole run of the column (state.py:200-239):
+//        holes += g_j,  column transitions += 2 [g_j > 0],  hole depth += (u_j + [g_j > 0]) n_j
+//    with u_j the hole-run tops of the old column, hole mask |= rows h_j .. a+b_j-1.  NO table;
+//  * row transitions of the footprint columns and of the column to their right: col_rowtrans on the
+//    new columns (a popcount each, no table);
+//  * wells of the footprint columns and of both neighbours: col_wells_packed on the new columns, one
+//    LDS read per 12-row chunk.
+// Rounds 1-2 re-read the hole tables for every footprint column and three byte tables per chunk for
+// the wells: 28 LDS reads per placement with 3-4-way bank conflicts on random indices, on the one LDS
+// pipe four SIMDs share -- that pipe, not the vector ALUs, bounded the walk; this form issues 8-10.
+// (Tried and dropped in round 3: the wells difference from a 4-row window table -- one read per
+// column but twice the vector instructions -- and one lane per (env, column) with LDS-staged
+// contiguous stores: 5-9 x the wave instructions per env.  profiles/r03_experiments/.)
+// Placements that complete a row (about 1 %) take the full evaluation afterwards.
+// `lut` is an AfterLut.
 template <typename W, int C, int NCH, typename Emit>
-TET_HD void afterstates_env(const W (&col)[C], uint64_t meta, const SetTable& tab, const uint8_t* hole_lut, int R,
+TET_HD void afterstates_env(const W (&col)[C], uint64_t meta, const SetTable& tab, const uint8_t* lut, int R,
                             Emit&& emit) {
+  const uint32_t* pack = reinterpret_cast<const uint32_t*>(lut + AfterLut::kWellsPack);
   int h[C];
   heights_of<W, C>(col, h);
   const W wall = lowmask<W>(R + 4);
   const int piece = meta_piece(meta);
   const uint64_t full = tab.fullmask[piece];
-  // per-column terms of the current board, packed to keep the register count down:
-  //   TA = col_trans (10 bits) | holes << 10 (10 bits) | row_trans << 20 (12 bits)
-  //   TB = wells (16 bits) | hole_depth << 16
-  // (field widths hold the whole-board sums for up to 60 stored rows x 10 columns)
+  // per-column terms of the current board:  D = u | nh << 5 | rt << 11 | wells << 18
+  // (hole-run tops <= 22, holes <= 43, row-transition term <= 88, wells <= 990 on 44 stored rows)
   W HO[C];
-  uint32_t TA[C], TB[C];
-  uint32_t sA = (uint32_t)C, sB = 0;  // column_transitions starts at one per column (state.py:194)
+  uint32_t D[C];
+  int sF1 = C;  // one unconditional transition per column (state.py:194)
+  int sHoles = 0, sF7 = 0, sWells = 0;
+  int sRT = R - popc(col[C - 1]);  // state.py:190
   {
     int nh_left = 0;
 #pragma unroll
@@ -804,152 +883,147 @@ TET_HD void afterstates_env(const W (&col)[C], uint64_t meta, const SetTable& ta
       const W Rr = (i == C - 1) ? wall : col[i + 1];
       const int hL = (i == 0) ? R : h[i - 1];
       int nh, e1, e7;
-      col_own<W, NCH>(col[i], h[i], R, hole_lut, HO[i], nh, e1, e7);
+      col_own<W, NCH, 12>(col[i], h[i], R, lut, HO[i], nh, e1, e7);
       const int e5 = col_rowtrans<W>(col[i], L, h[i], hL, nh_left);
-      const int e4 = col_wells<W, NCH>(col[i], L, Rr, h[i], R, i == 0, i == C - 1, hole_lut);
+      const int e4 = col_wells_packed<W, NCH>(col[i], L, Rr, h[i], R, i == 0, i == C - 1, pack);
       nh_left = nh;
-      TA[i] = (uint32_t)e1 | ((uint32_t)nh << 10) | ((uint32_t)e5 << 20);
-      TB[i] = (uint32_t)e4 | ((uint32_t)e7 << 16);
-      sA += TA[i];
-      sB += TB[i];
+      D[i] = (uint32_t)(e1 >> 1) | ((uint32_t)nh << 5) | ((uint32_t)e5 << 11) | ((uint32_t)e4 << 18);
+      sF1 += e1;
+      sHoles += nh;
+      sF7 += e7;
+      sRT += e5;
+      sWells += e4;
     }
   }
-  const int plast = popc(col[C - 1]);
   uint64_t slow = 0;  // placements that clear lines: evaluated in full below
-  // Slots are walked in the reference's enumeration order (loop L, column c, orientation o) so
-  // that consecutive calls of emit produce consecutive feature rows: the four 32-byte rows that
-  // share a 128-byte line are then stored within a few hundred instructions of each other and
-  // merge in L2.  (Walking orientation-major left every line half written for thousands of
-  // cycles; the partially written lines were evicted and HBM took them at half rate.)
 #pragma unroll 1
   for (int L = 0; L < 2; ++L) {
     const uint32_t d0 = tab.orient[piece][2 * L].desc, d1 = tab.orient[piece][2 * L + 1].desc;
     if (!TET_WAVE_ANY((d0 | d1) >> 31)) continue;
     // widest footprint of each orientation over the wave: narrower pieces skip the extra columns
-    const bool v01 = TET_WAVE_ANY((d0 & 7u) > 1), v02 = TET_WAVE_ANY((d0 & 7u) > 2), v03 = TET_WAVE_ANY((d0 & 7u) > 3);
-    const bool v11 = TET_WAVE_ANY((d1 & 7u) > 1), v12 = TET_WAVE_ANY((d1 & 7u) > 2), v13 = TET_WAVE_ANY((d1 & 7u) > 3);
+    const int wu0 = 1 + (TET_WAVE_ANY((d0 & 7u) > 1) ? 1 : 0) + (TET_WAVE_ANY((d0 & 7u) > 2) ? 1 : 0) +
+                    (TET_WAVE_ANY((d0 & 7u) > 3) ? 1 : 0);
+    const int wu1 = 1 + (TET_WAVE_ANY((d1 & 7u) > 1) ? 1 : 0) + (TET_WAVE_ANY((d1 & 7u) > 2) ? 1 : 0) +
+                    (TET_WAVE_ANY((d1 & 7u) > 3) ? 1 : 0);
 #pragma unroll
     for (int c = 0; c < C; ++c) {
-// both orientations of a column in one straight-line block: the two evaluations are independent, and
-// at the two waves per SIMD this walk runs at (it is bound by latency, not by issue) the extra
-// instruction-level parallelism is worth 4 % on the afterstate matrix and 10 % on the greedy policy
-#ifndef TET_AFTER_UNROLL_OI
-#define TET_AFTER_UNROLL_OI 2
-#endif
-#pragma unroll TET_AFTER_UNROLL_OI
-     for (int oi = 0; oi < 2; ++oi) {
-      const int k = 2 * L + oi;
-      const Orient o = unpack_orient(oi ? d1 : d0);
-      const bool u1 = oi ? v11 : v01, u2 = oi ? v12 : v02, u3 = oi ? v13 : v03;
-      const int s = mask_bit(k, c);
-      const bool ex = (full >> s) & 1;  // this lane's piece has this placement
-      if (!TET_WAVE_ANY(ex)) continue;
-      int a = 0;
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (c + j < C) {
-          const int v = (j < o.w) ? h[c + j] - o.b[j] : 0;
-          a = v > a ? v : a;
-        }
-      W nb[4];
-      int nhh[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int nj = (j < o.w) ? o.n[j] : 0;
-        const W pb = (W)(lowmask<W>(nj) << (a + o.b[j]));
-        nb[j] = (c + j < C) ? (W)(col[c + j] | pb) : (W)0;
-        nhh[j] = (c + j < C) ? ((j < o.w) ? a + o.b[j] + o.n[j] : h[c + j]) : 0;
-      }
-      W F = (W)((W)~(W)0 << a);  // rows of the piece only (see clear_lines)
-#pragma unroll
-      for (int i = 0; i < C; ++i) F &= (i >= c && i < c + 4) ? nb[i - c] : col[i];
-      const bool fast = ex && F == 0;
-      if (ex && F != 0) slow |= 1ull << s;
-      if (!TET_WAVE_ANY(fast)) continue;
-      // clamp helpers keep every array index static and in range even in dead branches
-      constexpr int kz = 0;
-      const int cm1 = c >= 1 ? c - 1 : kz, cm2 = c >= 2 ? c - 2 : kz;
-      uint32_t dA = sA, dB = sB;
-      W hrows = 0;
+      // AND of the columns / OR of the hole masks outside the window c .. c+3 (shared by both orientations)
+      W a_ex = (W)~(W)0, o_ex = 0;
 #pragma unroll
       for (int i = 0; i < C; ++i)
-        if (i < c || i > c + 3) hrows |= HO[i];
-      if (c >= 1) {  // left neighbour: only its wells see the new column c
-        const W L2 = (c >= 2) ? col[cm2] : wall;
-        dB += (uint32_t)col_wells<W, NCH>(col[cm1], L2, nb[0], h[cm1], R, c == 1, false, hole_lut) - (TB[cm1] & 0xFFFFu);
-      }
-      int nhprev = (c >= 1) ? (int)((TA[cm1] >> 10) & 1023u) : 0;
+        if (i < c || i > c + 3) {
+          a_ex &= col[i];
+          o_ex |= HO[i];
+        }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int i = c + j < C ? c + j : C - 1;
-        if (c + j < C) {
-          const bool fullre = (j == 0) || (j == 1 ? u1 : (j == 2 ? u2 : u3));
-          const bool part = !fullre && (j == 1 ? true : (j == 2 ? u1 : u2));
-          const int jm = j >= 1 ? j - 1 : 0, jp = j + 1 < 4 ? j + 1 : 3, ip = i + 1 < C ? i + 1 : C - 1;
-          const W L = (j == 0) ? ((c >= 1) ? col[cm1] : wall) : nb[jm];
-          const int hL = (j == 0) ? ((c >= 1) ? h[cm1] : R) : nhh[jm];
-          const W Rr = (c + j + 1 < C) ? ((j + 1 < 4) ? nb[jp] : col[ip]) : wall;
-          if (fullre) {
-            W ho;
-            int nh, e1, e7;
-            col_own<W, NCH>(nb[j], nhh[j], R, hole_lut, ho, nh, e1, e7);
-            const int e5 = col_rowtrans<W>(nb[j], L, nhh[j], hL, nhprev);
-            const int e4 = col_wells<W, NCH>(nb[j], L, Rr, nhh[j], R, c + j == 0, c + j == C - 1, hole_lut);
-            dA += ((uint32_t)e1 | ((uint32_t)nh << 10) | ((uint32_t)e5 << 20)) - TA[i];
-            dB += ((uint32_t)e4 | ((uint32_t)e7 << 16)) - TB[i];
-            hrows |= ho;
-            nhprev = nh;
+      for (int oi = 0; oi < 2; ++oi) {
+        const int k = 2 * L + oi;
+        const uint32_t dsc = oi ? d1 : d0;
+        const int wu = oi ? wu1 : wu0;  // wave-uniform
+        const int wd = (int)(dsc & 7u), H = (int)((dsc >> 3) & 7u);
+        const int sbit = mask_bit(k, c);
+        const bool ex = (full >> sbit) & 1;  // this lane's piece has this placement
+        if (!TET_WAVE_ANY(ex)) continue;
+        int a = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (c + j < C) {
+            const int v = h[c + j] - (int)((dsc >> (6 + 5 * j)) & 3u);
+            a = (j < wd && v > a) ? v : a;
+          }
+        // window position q = column c - 1 + q: new columns, heights, hole counts
+        W XN[6];
+        int HN[6], NHN[5];
+        {
+          const int cm1 = c >= 1 ? c - 1 : 0, c4 = c + 4 < C ? c + 4 : C - 1;
+          XN[0] = (c >= 1) ? col[cm1] : wall;
+          HN[0] = (c >= 1) ? h[cm1] : R;
+          NHN[0] = (c >= 1) ? (int)((D[cm1] >> 5) & 63u) : 0;
+          XN[5] = (c + 4 < C) ? col[c4] : wall;
+          HN[5] = (c + 4 < C) ? h[c4] : R;
+        }
+        W hrows = o_ex, F = a_ex;
+        int dholes = 0, dtops = 0, df7 = 0, dlast = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          constexpr int kz = 0;
+          const int i = c + j < C ? c + j : kz;
+          if (c + j < C) {
+            const int bj = (int)((dsc >> (6 + 5 * j)) & 3u), nj = (int)((dsc >> (8 + 5 * j)) & 7u);  // nj = 0 beyond the piece
+            const int bot = (j < wd) ? a + bj : h[i];
+            const int g = bot - h[i];  // cells left empty under the piece in this column
+            XN[j + 1] = (W)(col[i] | (W)(lowmask<W>(nj) << bot));
+            HN[j + 1] = bot + nj;
+            hrows |= (W)(HO[i] | (W)(lowmask<W>(g) << h[i]));
+            const int top = g > 0 ? 1 : 0;
+            dholes += g;
+            dtops += top;
+            df7 += ((int)(D[i] & 31u) + top) * nj;
+            NHN[j + 1] = (int)((D[i] >> 5) & 63u) + g;
+            if (c + j == C - 1) dlast = nj;  // the right wall's term counts the cells of the last column
+            F &= XN[j + 1];
           } else {
-            hrows |= HO[i];
-            if (part) {  // right neighbour of the widest footprint in this wave
-              const int e5 = col_rowtrans<W>(col[i], L, h[i], hL, nhprev);
-              const int e4 = col_wells<W, NCH>(col[i], L, Rr, h[i], R, false, i == C - 1, hole_lut);
-              dA += ((uint32_t)e5 << 20) - (TA[i] & 0xFFF00000u);
-              dB += (uint32_t)e4 - (TB[i] & 0xFFFFu);
-            }
-            nhprev = (int)((TA[i] >> 10) & 1023u);
+            XN[j + 1] = wall;
+            HN[j + 1] = R;
+            NHN[j + 1] = 0;
           }
         }
+        F &= (W)((W)~(W)0 << a);  // rows of the piece only (see clear_lines)
+        const bool fast = ex && F == 0;
+        if (ex && F != 0) slow |= 1ull << sbit;
+        if (!TET_WAVE_ANY(fast)) continue;
+        // row transitions of columns c .. c+wu (the left neighbour of c+wu may have changed)
+        int drt = 0;
+#pragma unroll
+        for (int q = 1; q <= 5; ++q)
+          if (c + q - 1 < C && q <= wu + 1) {
+            constexpr int kz = 0;
+            const int i = c + q - 1 < C ? c + q - 1 : kz;
+            drt += col_rowtrans<W>(XN[q], XN[q - 1], HN[q], HN[q - 1], NHN[q - 1]) - (int)((D[i] >> 11) & 127u);
+          }
+        // wells of columns c-1 .. c+wu
+        int dwells = 0;
+#pragma unroll
+        for (int q = 0; q <= 5; ++q)
+          if (c + q - 1 >= 0 && c + q - 1 < C && q <= wu + 1) {
+            constexpr int kz = 0;
+            const int i = (c + q - 1 >= 0 && c + q - 1 < C) ? c + q - 1 : kz;
+            const int il = (i - 1 >= 0) ? i - 1 : kz, ir = (i + 1 < C) ? i + 1 : C - 1;
+            const W Lq = (q >= 1) ? XN[q - 1] : ((i >= 1) ? col[il] : wall);
+            const W Rq = (q <= 4) ? XN[q + 1] : ((i + 1 < C) ? col[ir] : wall);
+            dwells += col_wells_packed<W, NCH>(XN[q], Lq, Rq, HN[q], R, i == 0, i == C - 1, pack) - (int)(D[i] >> 18);
+          }
+        float f[8];
+        f[0] = (float)popc(hrows);
+        f[1] = (float)(sF1 + 2 * dtops);
+        f[2] = (float)(sHoles + dholes);
+        f[3] = (float)a + 0.5f * (float)(H - 1) + 1.0f;  // state.py:102 with the pre-clear anchor row
+        f[4] = (float)(sWells + dwells);
+        f[5] = (float)(sRT + drt - dlast);
+        f[6] = 0.0f;
+        f[7] = (float)(sF7 + df7);
+        emit(fast, k, c, f);
+        TET_SCHED_FENCE();  // one placement at a time: interleaving the unrolled columns only costs registers
       }
-      if (c + 4 < C && u3) {  // right neighbour of a 4-wide footprint
-        const int i = c + 4 < C ? c + 4 : C - 1, ip = i + 1 < C ? i + 1 : C - 1;
-        const W Rr = (c + 5 < C) ? col[ip] : wall;
-        dA += ((uint32_t)col_rowtrans<W>(col[i], nb[3], h[i], nhh[3], nhprev) << 20) - (TA[i] & 0xFFF00000u);
-        dB += (uint32_t)col_wells<W, NCH>(col[i], nb[3], Rr, h[i], R, false, i == C - 1, hole_lut) - (TB[i] & 0xFFFFu);
-      }
-      const int lj = (C - 1 - c >= 0 && C - 1 - c < 4) ? C - 1 - c : 0;
-      const int pl = (C - 1 >= c && C - 1 < c + 4) ? popc(nb[lj]) : plast;
-      float f[8];
-      f[0] = (float)popc(hrows);
-      f[1] = (float)(dA & 1023u);
-      f[2] = (float)((dA >> 10) & 1023u);
-      f[3] = (float)a + 0.5f * (float)(o.H - 1) + 1.0f;
-      f[4] = (float)(dB & 0xFFFFu);
-      f[5] = (float)(R - pl + (int)(dA >> 20));
-      f[6] = 0.0f;
-      f[7] = (float)(dB >> 16);
-      emit(fast, k, c, f);
-      TET_SCHED_FENCE();  // one placement at a time: interleaving the unrolled columns only costs registers
-     }
     }
   }
   while (TET_WAVE_ANY(slow != 0) && !(TET_ABLATE & 256)) {  // line-clearing placements (rare): full evaluation, state.py:33 onwards
     const bool has = slow != 0;  // lanes that are done keep pace on placement 0 (it always exists)
-    const int s = has ? bitlen(slow) - 1 : 0;
-    slow &= ~(1ull << s);
+    const int sb = has ? bitlen(slow) - 1 : 0;
+    slow &= ~(1ull << sb);
     W fb[C];
 #pragma unroll
     for (int i = 0; i < C; ++i) fb[i] = col[i];
     W pbits[4];
     int fh[C];
-    const int sk = s / kFieldStride, sc = s - sk * kFieldStride;
+    const int sk = sb / kFieldStride, sc = sb - sk * kFieldStride;
     const uint32_t od = tab.orient[piece][sk].desc;
     const int aa = stamp_dynamic<W, C>(fb, h, sc, od, pbits);
     int eroded = 0;
     const int kk = clear_lines<W, C>(fb, pbits, aa, &eroded);
     heights_of<W, C>(fb, fh);
     float f[8];
-    bcts_features<W, C, NCH>(fb, fh, R, hole_lut, aa, (int)((od >> 3) & 7u), eroded, kk, f);
+    bcts_features<W, C, NCH, 12, true>(fb, fh, R, lut, aa, (int)((od >> 3) & 7u), eroded, kk, f);
     emit(has, sk, sc, f);
   }
 }
@@ -997,7 +1071,8 @@ TET_HD int policy_random(uint32_t key_policy, uint32_t env, int n_valid) {
 
 // `action` < 0 with use_policy: draw it with policy_random.  `draw` = replay piece for the
 // step draw (or -1: use the bag), `draw_reset` = replay piece for the reset draw (or -1).
-template <typename W, int C, int NCH = 0, int CR = 12>
+// PACKW: hole_lut is an AfterLut (kernels whose policy walks the afterstates) instead of a LutLayout<CR>
+template <typename W, int C, int NCH = 0, int CR = 12, bool PACKW = false>
 TET_HD void env_step(W (&col)[C], uint64_t& meta, int action, bool use_policy, const SetTable& tab,
                      const uint8_t* hole_lut, W* scratch, int sstride, const StepCfg& cfg, uint32_t env, int draw,
                      int draw_reset, StepOut& out) {
@@ -1021,7 +1096,7 @@ TET_HD void env_step(W (&col)[C], uint64_t& meta, int action, bool use_policy, c
   }
   // decode action -> (orientation field, left column): game.py:69,83
   int sk, c;
-  slot_of_action_lut<C>(mask, action, hole_lut + LutLayout<CR>::kSelPair, sk, c);
+  slot_of_action_lut<C>(mask, action, hole_lut + (PACKW ? AfterLut::kSelPair : LutLayout<CR>::kSelPair), sk, c);
   const uint32_t od = tab.orient[piece][sk].desc;
   const int oH = (od >> 3) & 7;
 
@@ -1035,7 +1110,7 @@ TET_HD void env_step(W (&col)[C], uint64_t& meta, int action, bool use_policy, c
 #pragma unroll
     for (int i = 0; i < 8; ++i) out.obs[i] = (float)h[i < C ? i : C - 1];  // placeholder: obs is not stored
   } else
-  bcts_features<W, C, NCH, CR>(col, h, R, hole_lut, a, oH, eroded, k, out.obs);  // game.py:91
+  bcts_features<W, C, NCH, CR, PACKW>(col, h, R, hole_lut, a, oH, eroded, k, out.obs);  // game.py:91
   if (cfg.has_direct_by) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) out.obs[i] *= cfg.direct_by[i];
@@ -1043,7 +1118,7 @@ TET_HD void env_step(W (&col)[C], uint64_t& meta, int action, bool use_policy, c
   // game.py:87 next piece, :88 is_game_over for THAT piece.  One hash feeds both draws of
   // the step: high 16 bits the step draw, low 16 bits the reset draw.
   const uint32_t rnd = hash_env(cfg.key_step, env);
-  const uint8_t* sel_nib = hole_lut + LutLayout<CR>::kSelNib;
+  const uint8_t* sel_nib = hole_lut + (PACKW ? AfterLut::kSelNib : LutLayout<CR>::kSelNib);
   int np = draw >= 0 ? draw : bag_draw_lut(bag, cfg.n_pieces, rnd >> 16, sel_nib);
   uint64_t nmask = (TET_ABLATE & 2) ? (tab.fullmask[np] ^ (uint64_t)h[0])
                                     : valid_mask<W, C>(col, h, piece_entries(tab, np), tab.fullmask[np], R);
@@ -1117,7 +1192,7 @@ TET_HD int rollout_env(const W (&col0)[C], uint64_t meta0, int a0, int length, i
       }
     }
     StepOut out;
-    env_step<W, C, NCH>(col, meta, action, use_policy, tab, hole_lut, scratch, sstride, cfg, uid, -1, -1, out);
+    env_step<W, C, NCH, 12, true>(col, meta, action, use_policy, tab, hole_lut, scratch, sstride, cfg, uid, -1, -1, out);
     if (out.done || out.invalid) return -1;  // game.py:135-138,143-145
     if (t > 0) ret += out.reward;
   }

@@ -79,18 +79,31 @@ struct alignas(16) FeatureLut10 {
 __device__ const FeatureLut10 kFeatureLut10 = {{
 #include "tetris_feature_lut10.inc"
 }};
+// tables of the kernels that walk the afterstates (tet::AfterLut: hole tables, packed wells entries, select tables)
+struct alignas(16) AfterLutData {
+  uint8_t bytes[tet::kAfterLutBytes];
+};
+__device__ const AfterLutData kAfterLut = {{
+#include "tetris_after_lut.inc"
+}};
+static_assert(tet::kAfterLutBytes % 16 == 0, "staged as uint4");
 template <int CR>
 __device__ __forceinline__ const uint4* feature_lut_src() {
   return CR == 10 ? reinterpret_cast<const uint4*>(&kFeatureLut10) : reinterpret_cast<const uint4*>(&kFeatureLut);
+}
+__device__ __forceinline__ void stage_after_lut(uint8_t* lds) {
+  const uint4* src = reinterpret_cast<const uint4*>(&kAfterLut);
+  uint4* dst = reinterpret_cast<uint4*>(lds);
+  for (int t = threadIdx.x; t < tet::kAfterLutBytes / 16; t += blockDim.x) dst[t] = src[t];
 }
 
 // Everything a stepping workgroup keeps in LDS, as ONE object so that the placement table sits at
 // LDS address 0: its reads then fit the 8-bit offsets of ds_read2 / the offset field of
 // ds_read_b128 and need no per-read address arithmetic.
-template <typename W, int C, int BLK, int CR>
+template <typename W, int C, int BLK, int CR, bool AFTER = false>
 struct alignas(16) StepLds {
   SetTable tab;
-  alignas(16) uint8_t lut[tet::LutLayout<CR>::kBytes];
+  alignas(16) uint8_t lut[AFTER ? tet::kAfterLutBytes : tet::LutLayout<CR>::kBytes];  // AFTER: a tet::AfterLut
   W lane_cols[C][BLK];  // per-lane scratch for the runtime-indexed stamp (bank = lane)
 };
 
@@ -135,6 +148,11 @@ struct StepParams {
   uint8_t* n_valid;
   uint8_t* piece_next;
   uint32_t* status;
+  // payload of the done/reset gather, written by the step itself when given: one 64-bit done
+  // mask per wavefront (bit = lane) and a copy of the wavefront's counter slot as of THIS step -- a
+  // consistent snapshot in memory no later step touches, so the exchange can run beside the next steps
+  unsigned long long* done_bits;
+  uint32_t* status_snapshot;
   uint32_t B;
   uint32_t env_offset;     // global env index of env 0 (mod 2^32)
   // step index from device memory (HIP-graph replays: the kernel arguments of a captured launch are
@@ -298,9 +316,10 @@ __global__ __launch_bounds__(step_block<W>(), (step_waves<W, CR>())) void step_k
     if (p.piece_next) st_off(p.piece_next, i, (uint8_t)out.piece);
     if (p.action_out) st_off(p.action_out, i * 4u, (int32_t)out.action);
   }
-  if (p.status) {
+  if (p.status || p.done_bits) {
+    const unsigned long long done_mask = __ballot(done != 0);
     const unsigned n_inv = wave_sum(1, invalid);
-    const unsigned n_done = wave_sum(1, done);
+    const unsigned n_done = (unsigned)__popcll(done_mask);
     const unsigned n_lines = wave_sum(3, lines);
     const unsigned n_steps = wave_sum(1, (live && !invalid) ? 1 : 0);
     if ((threadIdx.x & 63) == 0) {
@@ -309,7 +328,9 @@ __global__ __launch_bounds__(step_block<W>(), (step_waves<W, CR>())) void step_k
       v.y += n_done;
       v.z += n_lines;
       v.w += n_steps;
-      st_off(reinterpret_cast<uint4*>(p.status), (i >> 6) * 16u, v);
+      if (p.status) st_off(reinterpret_cast<uint4*>(p.status), (i >> 6) * 16u, v);
+      if (p.status_snapshot) st_off(reinterpret_cast<uint4*>(p.status_snapshot), (i >> 6) * 16u, v);
+      if (p.done_bits) st_off(p.done_bits, (i >> 6) * 8u, done_mask);
     }
   }
 #if TET_STAMPS
@@ -322,6 +343,25 @@ __global__ __launch_bounds__(step_block<W>(), (step_waves<W, CR>())) void step_k
   }
 #endif
 }
+
+// Minimum waves per SIMD the kernels built on tet::afterstates_env are compiled for (= their VGPR budget),
+// measured per kernel at 1 Mi envs (profiles/r03_experiments/afterstates_family_waves_sweep.txt).  32-bit
+// boards: the afterstate matrix kernel is bound by its row stores and runs best unconstrained (2: ~200
+// VGPRs, no spills: 0.43 ms against 0.49 / 0.73 at 3 / 4); the greedy policy kernel at 3 (0.255 ms against
+// 0.31 / 0.29 at 2 / 4); the kernels that also step (K greedy steps per launch, rollouts) at 4 (128 VGPRs, a
+// few spilled dwords: 0.27 ms per step against 0.33 / 0.29, 9.5 ms against 12.8 / 10.6).  64-bit boards
+// (10x40): 2 everywhere -- at 3 the 168-VGPR budget spills 600-870 bytes and every kernel is 1.3-2 x slower.
+#ifndef TET_AFTER_WAVES
+#define TET_AFTER_WAVES 2
+#endif
+#ifndef TET_GREEDY_WAVES
+#define TET_GREEDY_WAVES 3
+#endif
+#ifndef TET_STEP_GREEDY_WAVES
+#define TET_STEP_GREEDY_WAVES 4
+#endif
+template <typename W>
+constexpr int after_waves(int want) { return sizeof(W) == 4 ? want : (want > 2 ? 2 : want); }
 
 struct StepManyParams {
   StepParams one;        // pointers of step 0; per-step outputs advance by B elements per step
@@ -337,11 +377,12 @@ struct StepManyParams {
 // step's outputs are written to trajectory buffers [K][B]...; bit-identical to K launches of
 // step_kernel with step_idx0, step_idx0 + 1, ...  (the per-step keys are re-derived on device).
 template <typename W, int C, int NCH, int POLICY, int CR>
-__global__ __launch_bounds__(step_block<W>(), (POLICY == 0 ? step_waves<W, CR>() : 1)) void step_many_kernel(const StepManyParams q) {
+__global__ __launch_bounds__(step_block<W>(), (POLICY == 0 ? step_waves<W, CR>() : after_waves<W>(TET_STEP_GREEDY_WAVES))) void step_many_kernel(const StepManyParams q) {
   static_assert(POLICY == 0 || CR == 12, "the greedy policy evaluates terminal afterstates too: 12-row chunks");
   constexpr int kBlock = step_block<W>();  // shadows the file-wide tile size inside this kernel
   const StepParams& p = q.one;
-  __shared__ StepLds<W, C, kBlock, CR> lds;
+  constexpr bool AFTER = POLICY == 1;  // the greedy policy walks the afterstates: tet::AfterLut tables
+  __shared__ StepLds<W, C, kBlock, CR, AFTER> lds;
   SetTable& tab = lds.tab;
   uint8_t* const hole_lut = lds.lut;
   W (&lane_cols)[C][kBlock] = lds.lane_cols;
@@ -350,7 +391,8 @@ __global__ __launch_bounds__(step_block<W>(), (POLICY == 0 ? step_waves<W, CR>()
   constexpr bool PACK = NCH != 0 && !TET_NO_PACK;
   StepInputs<W, C> in;
   load_inputs<W, C, PACK>(p, i, in);
-  stage_hole_lut<CR>(hole_lut);
+  if (AFTER) stage_after_lut(hole_lut);
+  else stage_hole_lut<CR>(hole_lut);
   stage_table(tab, p.tab);
   unsigned n_inv = 0, n_done = 0, n_lines = 0, n_steps = 0;
   StepCfg cfg = p.cfg;
@@ -381,8 +423,8 @@ __global__ __launch_bounds__(step_block<W>(), (POLICY == 0 ? step_waves<W, CR>()
         use_policy = false;
       }
       tet::StepOut out;
-      tet::env_step<W, C, NCH, CR>(in.col, in.meta, action, use_policy, tab, hole_lut, &lane_cols[0][threadIdx.x], kBlock,
-                               cfg, p.env_offset + i, -1, -1, out);
+      tet::env_step<W, C, NCH, CR, AFTER>(in.col, in.meta, action, use_policy, tab, hole_lut, &lane_cols[0][threadIdx.x],
+                                          kBlock, cfg, p.env_offset + i, -1, -1, out);
       invalid = out.invalid;
       const uint32_t e = (uint32_t)k * p.B + i;  // element index in the [K][B] trajectory buffers
       if (p.obs) {
@@ -510,9 +552,7 @@ struct AfterParams {
 
 // game.py:67-80.  One lane per env walks the static slots in reference order;
 // the k-th non-terminal placement lands in feats[i][k].
-#ifndef TET_AFTER_WAVES
-#define TET_AFTER_WAVES 1
-#endif
+
 
 // Feature rows are 32 bytes and the rows of different envs are far apart, so a plain store of one
 // row per lane is 64 separate 16-byte write requests per instruction -- the kernel was bound by
@@ -544,10 +584,10 @@ __device__ __forceinline__ void store_row_paired(float* base, bool has, uint32_t
 }
 
 template <typename W, int C, int NCH>
-__global__ __launch_bounds__(kBlock, TET_AFTER_WAVES) void afterstates_kernel(const AfterParams p) {
+__global__ __launch_bounds__(kBlock, (after_waves<W>(TET_AFTER_WAVES))) void afterstates_kernel(const AfterParams p) {
   __shared__ SetTable tab;
-  __shared__ __attribute__((aligned(16))) uint8_t hole_lut[tet::kFeatureLutBytes];
-  stage_hole_lut(hole_lut);
+  __shared__ __attribute__((aligned(16))) uint8_t hole_lut[tet::kAfterLutBytes];
+  stage_after_lut(hole_lut);
   stage_table(tab, p.tab);
   const int64_t i0 = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   const bool live = i0 < p.B;
@@ -599,6 +639,7 @@ __global__ __launch_bounds__(kBlock, TET_AFTER_WAVES) void afterstates_kernel(co
   }
 }
 
+
 struct GreedyParams {
   const void* cols;
   const uint64_t* meta;
@@ -616,10 +657,10 @@ struct GreedyParams {
 // placement (raw order, terminal included, like game.py:103) and the best NON-terminal action.
 // The [B][a_max][8] feature matrix never touches HBM.
 template <typename W, int C, int NCH>
-__global__ __launch_bounds__(kBlock) void greedy_kernel(const GreedyParams p) {
+__global__ __launch_bounds__(kBlock, (after_waves<W>(TET_GREEDY_WAVES))) void greedy_kernel(const GreedyParams p) {
   __shared__ SetTable tab;
-  __shared__ __attribute__((aligned(16))) uint8_t hole_lut[tet::kFeatureLutBytes];
-  stage_hole_lut(hole_lut);
+  __shared__ __attribute__((aligned(16))) uint8_t hole_lut[tet::kAfterLutBytes];
+  stage_after_lut(hole_lut);
   stage_table(tab, p.tab);
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= p.B) return;
@@ -670,13 +711,16 @@ struct RolloutParams {
 
 // Tetris.perform_rollouts (game.py:150-160) as a fan-out: one lane per (env, first action) runs its
 // n rollouts back to back with the board in registers; nothing but the mean returns is written.
+// 512 lanes per workgroup: with the 35 KiB of afterstate tables two workgroups = 16 waves fit a CU
+constexpr int kRolloutBlock = 512;
 template <typename W, int C, int NCH>
-__global__ __launch_bounds__(kBlock) void rollouts_kernel(const RolloutParams p) {
-  __shared__ StepLds<W, C, kBlock, 12> lds;
+__global__ __launch_bounds__(kRolloutBlock, (after_waves<W>(TET_STEP_GREEDY_WAVES))) void rollouts_kernel(const RolloutParams p) {
+  constexpr int kBlock = kRolloutBlock;  // shadows the file-wide tile size inside this kernel
+  __shared__ StepLds<W, C, kBlock, 12, true> lds;
   SetTable& tab = lds.tab;
   uint8_t* const hole_lut = lds.lut;
   W (&lane_cols)[C][kBlock] = lds.lane_cols;
-  stage_hole_lut(hole_lut);
+  stage_after_lut(hole_lut);
   stage_table(tab, p.tab);
   const int64_t id = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (id >= p.B * p.a_max) return;
@@ -807,6 +851,7 @@ __global__ __launch_bounds__(kBlock) void encode_kernel(const int8_t* __restrict
 // ---- dispatch on (word, C) -------------------------------------------------------
 
 inline dim3 grid_for(int64_t B) { return dim3((unsigned)((B + kBlock - 1) / kBlock)); }
+inline dim3 rollout_grid(int64_t n) { return dim3((unsigned)((n + kRolloutBlock - 1) / kRolloutBlock)); }
 template <typename W>
 inline dim3 step_grid(int64_t B) { return dim3((unsigned)((B + step_block<W>() - 1) / step_block<W>())); }
 
@@ -882,9 +927,9 @@ template <typename W, int C>
 struct LaunchRollouts {
   static void run(const RolloutParams& p, hipStream_t s) {
     if (packed_geometry<W>(p.R))
-      hipLaunchKernelGGL((rollouts_kernel<W, C, packed_chunks<W>()>), grid_for(p.B * p.a_max), dim3(kBlock), 0, s, p);
+      hipLaunchKernelGGL((rollouts_kernel<W, C, packed_chunks<W>()>), rollout_grid(p.B * p.a_max), dim3(kRolloutBlock), 0, s, p);
     else
-      hipLaunchKernelGGL((rollouts_kernel<W, C, 0>), grid_for(p.B * p.a_max), dim3(kBlock), 0, s, p);
+      hipLaunchKernelGGL((rollouts_kernel<W, C, 0>), rollout_grid(p.B * p.a_max), dim3(kRolloutBlock), 0, s, p);
   }
 };
 template <typename W, int C>
@@ -1044,7 +1089,7 @@ int tetris_hip_reset(const TetrisDesc* desc, void* cols, uint64_t* meta, const u
   if (!cols || !meta) return TETRIS_E_NULL;
   if (B <= 0) return TETRIS_E_BATCH;
   if (stream && (!cursor || stream_len <= 0)) return TETRIS_E_STREAM;
-  ResetParams p;
+  ResetParams p{};
   p.cols = cols;
   p.meta = meta;
   p.reset_mask = reset_mask;
@@ -1075,7 +1120,7 @@ int tetris_hip_step_many(const TetrisDesc* desc, void* cols, uint64_t* meta, int
                          int32_t auto_reset, uint64_t seed, uint64_t step_idx0, int64_t env_offset, int64_t B,
                          void* hip_stream) {
   if (n_steps < 1 || policy < 0 || policy > 1 || (policy == 1 && !weights)) return TETRIS_E_BATCH;
-  StepManyParams q;
+  StepManyParams q{};
   int rc = fill_step_params(q.one, desc, cols, meta, nullptr, action_out, nullptr, nullptr, 0, obs, reward, done,
                             lines, n_valid_next, piece_next, status, auto_reset, seed, step_idx0, env_offset, B,
                             (int64_t)B * n_steps);
@@ -1093,7 +1138,7 @@ int tetris_hip_step(const TetrisDesc* desc, void* cols, uint64_t* meta, const in
                     uint8_t* done, uint8_t* lines, uint8_t* n_valid_next, uint8_t* piece_next, uint32_t* status,
                     int32_t auto_reset, uint64_t seed, uint64_t step_idx, int64_t env_offset, int64_t B,
                     void* hip_stream) {
-  StepParams p;
+  StepParams p{};
   int rc = fill_step_params(p, desc, cols, meta, action, action_out, stream, cursor, stream_len, obs, reward, done,
                             lines, n_valid_next, piece_next, status, auto_reset, seed, step_idx, env_offset, B, B);
   if (rc) return rc;
@@ -1125,6 +1170,8 @@ static int fill_step_params(StepParams& p, const TetrisDesc* desc, void* cols, u
   p.n_valid = n_valid_next;
   p.piece_next = piece_next;
   p.status = status;
+  p.done_bits = nullptr;        // (the gather payload is attached per call: tetris_hip_step_call_run_gather)
+  p.status_snapshot = nullptr;
   p.B = (uint32_t)B;
   p.env_offset = (uint32_t)env_offset;
   p.step_counter = nullptr;
@@ -1145,7 +1192,7 @@ static int fill_step_params(StepParams& p, const TetrisDesc* desc, void* cols, u
 // ---- bound step call: everything that does not change between steps is prepared once ------------
 struct TetrisStepCall {
   uint64_t magic;
-  StepParams p;
+  StepParams p{};
   TetrisDesc desc;
   uint64_t seed;
   int32_t* action_out;  // written only when the built-in policy draws the action
@@ -1217,7 +1264,7 @@ int tetris_hip_afterstates(const TetrisDesc* desc, const void* cols, const uint6
   if (rc) return rc;
   if (!cols || !meta || !feats || !n_valid) return TETRIS_E_NULL;
   if (B <= 0) return TETRIS_E_BATCH;
-  AfterParams p;
+  AfterParams p{};
   p.cols = cols;
   p.meta = meta;
   p.feats = feats;
@@ -1245,7 +1292,7 @@ int tetris_hip_policy_greedy(const TetrisDesc* desc, const void* cols, const uin
   if (rc) return rc;
   if (!cols || !meta || !weights || !best_action) return TETRIS_E_NULL;
   if (B <= 0) return TETRIS_E_BATCH;
-  GreedyParams p;
+  GreedyParams p{};
   p.cols = cols;
   p.meta = meta;
   p.best_action = best_action;
@@ -1266,7 +1313,7 @@ int tetris_hip_rollouts(const TetrisDesc* desc, const void* cols, const uint64_t
   if (rc) return rc;
   if (!cols || !meta || !returns || (policy == 1 && !weights)) return TETRIS_E_NULL;
   if (B <= 0 || length < 1 || n < 1 || policy < 0 || policy > 1) return TETRIS_E_BATCH;
-  RolloutParams p;
+  RolloutParams p{};
   p.cols = cols;
   p.meta = meta;
   p.returns = returns;
@@ -1290,7 +1337,7 @@ int tetris_hip_refresh(const TetrisDesc* desc, const void* cols, uint64_t* meta,
   if (rc) return rc;
   if (!cols || !meta) return TETRIS_E_NULL;
   if (B <= 0) return TETRIS_E_BATCH;
-  RefreshParams p;
+  RefreshParams p{};
   p.cols = cols;
   p.meta = meta;
   p.n_valid_out = n_valid_out;

@@ -22,6 +22,8 @@ for t in range(150):
 abl = int(os.environ.get("ABL_MASK", "0"))
 if abl:  # variant built by tools/ablate.py (ABL_COMPILE_ONLY=1 python tools/ablate.py <mask>)
     env._lib = _lib._Binding(ctypes.CDLL(os.path.join(ROOT, "build_variants", "libtetris_abl_%d.so" % abl)))
+if os.environ.get("TETRIS_VARIANT_LIB"):  # any variant library (full C-ABI)
+    env._lib = _lib._Binding(ctypes.CDLL(os.environ["TETRIS_VARIANT_LIB"]))
 res = {}
 for inc in (False, True):
     for _ in range(3):
