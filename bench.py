@@ -26,6 +26,7 @@ HIP-event kernel time.  `cpu_baseline` times the CPU oracle (a port, oracle/) on
 host's cores on a bounded sample, single-thread and all-core.
 """
 import argparse
+import ctypes
 import hashlib
 import json
 import os
@@ -63,16 +64,19 @@ def csrc_hash():
     return h.hexdigest()[:16]
 
 
-def load_traffic(columns, rows, pieces, envs):
+def load_traffic(columns, rows, pieces, envs, lib_hash=None):
     """HBM bytes per launch of the step kernel from the PMC passes of tools/profile_round.sh
     (profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, corrected on
     refresh_kernel as MI355X_MICROARCH.md's HBM section prescribes) -- only when that profile was taken
-    on THIS workload and THESE kernel sources (`csrc_hash`); a stale profile yields None."""
+    on THIS workload and on the kernels that are running: its `csrc_hash` must equal the hash compiled
+    into the LOADED library (tetris_hip_source_hash; `lib_hash`) -- a stale library next to fresh sources,
+    or the reverse, yields None."""
     p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         d = json.load(open(p))
+        want = lib_hash if lib_hash is not None else csrc_hash()
         if (d.get("columns", 10), d.get("rows", 20), d.get("pieces", "default"), d.get("envs")) == \
-                (columns, rows, pieces, envs) and d.get("csrc_hash") == csrc_hash():
+                (columns, rows, pieces, envs) and d.get("csrc_hash") == want:
             return d.get("step_kernel_hbm_bytes_per_launch")
     except Exception:
         pass
@@ -311,23 +315,48 @@ def run_rank(args, device=None):
 
     n_gathers = [0]
     n_bit_gathers = [0]
-    # The gathers: the small read of the flags / counters (a ballot-pack kernel, a column sum) runs in
-    # order on the stepping stream; the collective itself is issued on a side stream that waits for that
-    # read, so it overlaps the following steps and the stepping stream never waits for it -- the
-    # exchange is off the step's critical path, as section 8(e) of the survey describes it.  (Making
-    # the stepping stream wait on the side stream instead costs ~70 us per gather on this stack:
-    # cross-stream dependencies resolve in tens of microseconds, rocprofv3 kernel trace.)
-    side = torch.cuda.Stream(dev) if (dist_on and on_gpu and backend == "nccl") else None
+    # The gathers.  The payload -- done bitmask, per-wave counter slots -- is written by the step kernel
+    # itself (tetris_hip_step_call_run_gather) into one of two buffers nothing else touches, the side
+    # stream is linked behind that step with a device-scope event (tetris_hip_stream_link) and runs the
+    # collective there: the stepping stream enqueues nothing for a gather and never waits for one -- the
+    # exchange is off the step's critical path, as section 8(e) of the survey describes it.  (Round 2
+    # packed the flags with an extra kernel on the stepping stream and recorded a default, system-scope
+    # event: ~35 us of idle stepping stream per gather.)  With --fuse / --graph / --streams the payload
+    # comes from the separate pack kernel and a column sum instead.
+    gather_mode = os.environ.get("TETRIS_BENCH_GATHER_MODE", "side")  # experiments: "same" (collective on the stepping stream), "linkonly"
+    side = torch.cuda.Stream(dev) if (dist_on and on_gpu and backend == "nccl" and gather_mode != "same") else None
+    in_kernel_payload = fuse == 1 and graphs is None and S == 1
+    payloads = [env.gather_payload() for _ in range(2)] if (dist_on and in_kernel_payload) else None
+    payload_free = [None, None]  # event after the last collective that read buffer i
+    n_payload = [0]
 
-    def off_path(read, exchange):
-        payload = read()
+    def next_payload():
+        i = n_payload[0] & 1
+        n_payload[0] += 1
+        if payload_free[i] is not None:
+            payload_free[i].synchronize()  # (two gathers ago: long done)
+        return i, payloads[i]
+
+    def run_off_path(i, exchange):
         if side is None:
-            exchange(payload)
+            exchange()
             return
-        side.wait_stream(cur_stream())
-        payload.record_stream(side)
+        from tetris_amd import _lib
+        lib = _lib.load()
+        lib.check(lib.stream_link(ctypes.c_void_p(cur_stream().cuda_stream), ctypes.c_void_p(side.cuda_stream)),
+                  "tetris_hip_stream_link")
         with torch.cuda.stream(side):
-            exchange(payload)
+            if gather_mode != "linkonly":
+                exchange()
+            if i is not None:
+                payload_free[i] = torch.cuda.Event()
+                payload_free[i].record(side)
+
+    def off_path(read, exchange):  # fallback: payload produced by extra launches on the stepping stream
+        payload = read()
+        if side is not None:
+            payload.record_stream(side)
+        run_off_path(None, lambda: exchange(payload))
 
     def gather_counters_now():
         off_path(all_totals, gather.gather_counters)
@@ -337,34 +366,46 @@ def run_rank(args, device=None):
         off_path(lambda: pack_done_bits(all_done()), gather.gather_packed)
         n_bit_gathers[0] += 1
 
-    def one_step(t):
+    def one_step(t, bits=False):
+        counters = dist_on and t >= 0 and (t + 1) % max(1, args.gather_every // fuse) == 0
+        if payloads is not None and (bits or counters):
+            i, pl = next_payload()
+            envs[0].step(gather=pl)  # the step writes the payload from its epilogue
+
+            def exchange():
+                if bits:
+                    gather.gather_packed(pl["done_bits"][:(B + 7) // 8])
+                if counters:
+                    gather.gather_counters((pl["counters"].to(torch.int64) & 0xFFFFFFFF).sum(dim=0))
+            run_off_path(i, exchange)
+            n_gathers[0] += int(counters)
+            n_bit_gathers[0] += int(bits)
+            return
         if S == 1:
             shard_step(0)
         else:
             for k in range(S):
                 with on_stream(k):
                     shard_step(k)
-        if dist_on and t >= 0 and (t + 1) % max(1, args.gather_every // fuse) == 0:
+        if counters:
             gather_counters_now()
             n_gathers[0] += 1
+        if bits:
+            gather_bits_now()
 
     for t in range(args.warmup // fuse):
         one_step(t)
     if dist_on:  # every collective of the timed region once before it: RCCL sets up a kind of call at its first use
-        gather_bits_now()
-        gather_counters_now()
+        one_step(max(1, args.gather_every // fuse) - 1, bits=True)
     n_gathers[0] = 0
     n_bit_gathers[0] = 0
     barrier()
     t0 = time.perf_counter()
     n_calls = args.steps // fuse
     for t in range(n_calls):
-        one_step(t)
-        if dist_on and t == (n_calls - 1) // 2:
-            gather_bits_now()  # the done/reset gather over RCCL (midway: it overlaps the remaining steps)
-    if side is not None:
-        cur_stream().wait_stream(side)
-    sync()
+        # the done/reset gather over RCCL once, midway: it overlaps the remaining steps
+        one_step(t, bits=dist_on and t == (n_calls - 1) // 2)
+    sync()  # (device-wide: the side stream's collectives included; no cross-stream wait on the GPU)
     dt = time.perf_counter() - t0   # this rank's K steps + its gathers; the MAX over ranks is taken below
     barrier()
     if dist_on:
@@ -468,7 +509,9 @@ def run_rank(args, device=None):
         # S shard launches of B/S envs run beside each other during every period k_ms
         per_launch = 1 if graph_steps > 1 else fuse  # env-steps of every env per timed kernel launch
         achieved = alg * B * per_launch / (k_ms * 1e-3) / 1e9
-        traffic = None if (args.no_obs or fuse > 1 or S > 1) else load_traffic(args.columns, args.rows, args.pieces, B)
+        lib_hash = env._lib.source_hash()
+        traffic = None if (args.no_obs or fuse > 1 or S > 1) else load_traffic(args.columns, args.rows, args.pieces, B,
+                                                                             lib_hash)
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "kernel": "step_kernel" if fuse == 1 else (
@@ -482,7 +525,8 @@ def run_rank(args, device=None):
                         "WRITE_SIZE count: see frac_4Mi for the same kernel streaming from HBM" % (alg * B // 1000000)}
         if traffic is not None:
             roof["achieved_measured"] = traffic / (k_ms * 1e-3) / 1e9
-            roof["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc, csrc_hash %s)" % csrc_hash()
+            roof["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc, csrc_hash %s)" % lib_hash
+        roof["library_source_hash"] = lib_hash
         if dist_on:
             roof["kernel_ms_per_rank"] = {"min": min(k_all), "max": max(k_all)}
         if "kernel_ms_4Mi" in extras:
@@ -522,6 +566,7 @@ def run_rank(args, device=None):
         if dist_on:
             out["done_gather"] = {"ms_per_gather": gather_ms, "counter_gathers_in_timed_region": n_gathers[0],
                                   "bitmask_gathers_in_timed_region": n_bit_gathers[0],
+                                  "payload": "step kernel epilogue" if payloads is not None else "pack kernel + column sum",
                                   "note": "cpu_baseline and the extra roofline keys are emitted only at world == 1"}
         if "tall_10x40" in extras:
             out["tall_10x40"] = extras["tall_10x40"]

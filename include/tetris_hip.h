@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define TETRIS_HIP_ABI_VERSION 5
+#define TETRIS_HIP_ABI_VERSION 6
 
 #define TETRIS_MAX_PIECES 12
 #define TETRIS_MAX_COLUMNS 10
@@ -117,12 +117,16 @@ int tetris_hip_n_placements(int32_t catalogue_id, int32_t num_columns);
  *  piece_out / n_valid_out : uint8[B] or NULL, written for the envs that reset
  *  stream/cursor/stream_len : replay mode (piece list indices, [stream_len][B]
  *      plane-major, cursor int32[B] = next unread row); NULL = device bag
+ *  status : per-wave counters (as tetris_hip_step) or NULL.  Replay mode: a reset consumes one stream
+ *      row; an env whose cursor is at or past the end of the stream is left untouched and counted in
+ *      status[TETRIS_STATUS_INVALID] (like a step past the end: the recorded game is never continued
+ *      on a repeated last row)
  *  init_bag : also empty the bag (sampler construction, tetromino.py:13-15);
  *      0 keeps it, as the reference does across resets (game.py:50 vs 53-63)
  */
 int tetris_hip_reset(const TetrisDesc* desc, void* cols, uint64_t* meta, const uint8_t* reset_mask,
                      uint8_t* piece_out, uint8_t* n_valid_out, const uint8_t* stream,
-                     int32_t* cursor, int64_t stream_len, int32_t init_bag, uint64_t seed,
+                     int32_t* cursor, int64_t stream_len, uint32_t* status, int32_t init_bag, uint64_t seed,
                      uint64_t step_idx, int64_t env_offset, int64_t B, void* hip_stream);
 
 /*
@@ -154,8 +158,8 @@ int tetris_hip_reset(const TetrisDesc* desc, void* cols, uint64_t* meta, const u
  * Replay mode: a step consumes one stream row, two when it ends the episode under
  * auto_reset.  An env whose cursor cannot cover that (cursor + 1, or + 2 with auto_reset,
  * > stream_len) is treated exactly like an out-of-range action: untouched and counted as
- * invalid -- the recorded game is never continued with made-up pieces.  (tetris_hip_reset
- * past the end of the stream re-reads the last row; the next step then reports the env.)
+ * invalid -- the recorded game is never continued with made-up pieces (tetris_hip_reset past the
+ * end of the stream reports the env the same way).
  */
 int tetris_hip_step(const TetrisDesc* desc, void* cols, uint64_t* meta, const int32_t* action,
                     int32_t* action_out, const uint8_t* stream, int32_t* cursor, int64_t stream_len, float* obs,
@@ -182,6 +186,28 @@ int tetris_hip_step_call_init(void* call, const TetrisDesc* desc, void* cols, ui
                               uint32_t* status, int32_t auto_reset, uint64_t seed,
                               int64_t env_offset, int64_t B);
 int tetris_hip_step_call_run(void* call, const int32_t* action, uint64_t step_idx, void* hip_stream);
+
+/*
+ * The bound step that also writes the payload of the done/reset gather between GPUs (the
+ * path's only exchange) from its own epilogue, so that a gather costs the stepping stream no launch:
+ *  done_bits       : uint64[ceil(B / 64)] or NULL: bit l of word w = done flag of env 64 w + l (the bytes
+ *                    tetris_hip_pack_done_bits would produce from `done`)
+ *  status_snapshot : uint32[tetris_hip_status_words(B)] or NULL: the per-wave counter slots as of THIS
+ *                    step -- a consistent copy in memory no later step touches (the live `status` slots
+ *                    keep moving)
+ * Both buffers belong to the caller; hand each gather its own pair (double-buffer) and run the
+ * collective on another stream behind tetris_hip_stream_link.
+ */
+int tetris_hip_step_call_run_gather(void* call, const int32_t* action, uint64_t step_idx, uint64_t* done_bits,
+                                    uint32_t* status_snapshot, void* hip_stream);
+
+/* `to_stream` waits for everything enqueued on `from_stream` so far, through an event that releases to
+ * DEVICE scope (producer and consumer are kernels on this GPU; no system-scope cache write-back). */
+int tetris_hip_stream_link(void* from_stream, void* to_stream);
+
+/* hash of the kernel sources this library was built from (tetris_amd/build.py passes it to the
+ * compiler): measurements are only quoted for the library that produced them */
+const char* tetris_hip_source_hash(void);
 
 /*
  * The bound step with its step index in DEVICE memory, for HIP graphs: the arguments of a captured
@@ -247,12 +273,15 @@ int tetris_hip_policy_greedy(const TetrisDesc* desc, const void* cols, const uin
  * (game.py:133-146: -1 if the env is already over or dies at any step, else the sum of the
  * rewards of steps 2..length); NaN for a >= n_valid.
  *  policy  : 0 uniform random valid action, 1 greedy on `weights` (HOST pointer to 8 floats)
+ *  pieces  : NULL, or uint8[B][a_max][n][length]: the list index every step of every rollout draws
+ *            (game.py:87 inside single_rollout) -- a recorded run of the reference's sampler, for
+ *            exact replays of perform_rollouts on multi-piece sets
  * cols / meta are not modified (the reference restores the env after every rollout but lets
- * its global bag advance; here every rollout draws from its own fork of the env's bag).
+ * its global bag advance; with pieces == NULL every rollout draws from its own fork of the env's bag).
  */
 int tetris_hip_rollouts(const TetrisDesc* desc, const void* cols, const uint64_t* meta,
                         double* returns, int32_t length, int32_t n, int32_t policy,
-                        const float* weights, uint64_t seed, uint64_t step_idx,
+                        const float* weights, const uint8_t* pieces, uint64_t seed, uint64_t step_idx,
                         int64_t env_offset, int64_t B, void* hip_stream);
 
 /*

@@ -23,6 +23,10 @@ Fixture families:
                     global-RNG state after every call) and one-piece-set rollout
                     returns that pin the batched rollout kernel
   g8_render         print_board_to_string / State.__repr__ / piece reprs
+  g9_rollouts_fed   single_rollout returns on MULTI-piece sets together with the list index the
+                    reference's sampler handed out at every rollout step (the global bag advances
+                    from rollout to rollout): the batched kernel replays them through its
+                    host-fed piece input
 """
 import os
 import sys
@@ -473,6 +477,62 @@ def gen_rollouts(game, tetromino):
     return out
 
 
+def gen_rollouts_fed(game, tetromino):
+    """game.py:129-160 on multi-piece sets.  For near-top states: every valid first action x n rollouts of
+    `length` steps with the float32 greedy policy, the afterstate list refreshed before each single_rollout
+    (see gen_rollouts); recorded per rollout: its return and the piece (list index) every sampler call inside
+    it returned -- the reference's global bag keeps advancing, so consecutive rollouts see different
+    sequences.  tetris_hip_rollouts fed with those pieces must return the same means."""
+    out = {"weights": np.array(BCTS_W, np.float64)}
+    for tag, names, R, seed, length, n in (("default_9", None, 9, 41, 4, 3), ("standard7_11", STANDARD7, 11, 42, 3, 2)):
+        env = make_env(game, tetromino, 10, R, names, seed)
+        drawn = []
+        real_next = env.tetromino_sampler.next_tetromino
+
+        def next_tetromino():
+            t = real_next()
+            drawn.append(env.tetrominos.index(t))
+            return t
+        env.tetromino_sampler.next_tetromino = next_tetromino
+        arng = np.random.default_rng(700 + seed)
+        boards, cur, rets, fed, died = [], [], [], [], 0
+        while len(boards) < 20:
+            fv, _ = env.get_after_states()
+            _, _, done, _ = env.step(int(arng.integers(fv.shape[0])))
+            if done:
+                env.reset()
+                continue
+            tall = int(np.max(env.current_state.lowest_free_rows)) >= R - 3
+            if arng.random() < (0.25 if tall else 0.75):
+                continue
+            boards.append(cols_of(env.current_state.representation))
+            cur.append(env.tetrominos.index(env.current_tetromino))
+            fv, _ = env.get_after_states()
+            row = np.full(40, np.nan)
+            pcs = np.zeros((40, n, length), np.uint8)
+            for act in range(fv.shape[0]):
+                rr = []
+                for r in range(n):
+                    env.get_after_states()
+                    del drawn[:]
+                    rr.append(env.single_rollout(act, policy_greedy_f32, length))
+                    assert 1 <= len(drawn) <= length
+                    pcs[act, r, :len(drawn)] = drawn
+                    died += int(rr[-1] == -1)
+                row[act] = np.mean(rr)
+            rets.append(row)
+            fed.append(pcs)
+        out[tag + "_boards"] = np.array(boards, np.uint64)
+        out[tag + "_piece"] = np.array(cur, np.int8)
+        out[tag + "_returns"] = np.array(rets)
+        out[tag + "_fed"] = np.array(fed)
+        out[tag + "_length"] = np.int64(length)
+        out[tag + "_n"] = np.int64(n)
+        out[tag + "_rows"] = np.int64(R)
+        print("g9 %s: %d states, %d rollouts died" % (tag, len(boards), died))
+    return out
+
+
 def gen_render(game, state, tetromino, utils):
     """state.py:69-81 (State.__repr__ / print_board_to_string: the R legal rows) and utils.py:179-191
     (all R + 4 stored rows) on three states; repr of the pieces that define one."""
@@ -525,6 +585,8 @@ def main():
             gen_all_trajectories(game, tetromino)
         if "g7" in only:
             np.savez_compressed(os.path.join(HERE, "g7_rollouts.npz"), **gen_rollouts(game, tetromino))
+        if "g9" in only:
+            np.savez_compressed(os.path.join(HERE, "g9_rollouts_fed.npz"), **gen_rollouts_fed(game, tetromino))
         if "g8" in only:
             from tetris import utils
             np.savez_compressed(os.path.join(HERE, "g8_render.npz"), **gen_render(game, state, tetromino, utils))
@@ -543,6 +605,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, "g7_rollouts.npz"), **gen_rollouts(game, tetromino))
     from tetris import utils
     np.savez_compressed(os.path.join(HERE, "g8_render.npz"), **gen_render(game, state, tetromino, utils))
+    np.savez_compressed(os.path.join(HERE, "g9_rollouts_fed.npz"), **gen_rollouts_fed(game, tetromino))
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -127,14 +127,18 @@ void step_impl(const TetrisDesc* desc, void* cols_, uint64_t* meta, const int32_
 
 template <typename W, int C>
 void reset_impl(const TetrisDesc* desc, void* cols_, uint64_t* meta, const uint8_t* reset_mask, uint8_t* piece_out,
-                uint8_t* n_valid_out, const uint8_t* stream, int32_t* cursor, int64_t stream_len, int init_bag,
-                uint64_t seed, uint64_t step_idx, int64_t env_offset, int64_t B) {
+                uint8_t* n_valid_out, const uint8_t* stream, int32_t* cursor, int64_t stream_len, uint32_t* status,
+                int init_bag, uint64_t seed, uint64_t step_idx, int64_t env_offset, int64_t B) {
   tet::SetTable tab;
   tet::build_table(desc, &tab);
   const uint32_t key = tet::hash_key(seed, step_idx * 4u + 2u);
   W* cols = static_cast<W*>(cols_);
   for (int64_t i = 0; i < B; ++i) {
     if (reset_mask && !reset_mask[i]) continue;
+    if (stream && (cursor[i] < 0 || cursor[i] >= stream_len)) {  // exhausted replay stream: untouched, counted
+      if (status) status[(i >> 6) * 4 + TETRIS_STATUS_INVALID] += 1;
+      continue;
+    }
     {
       W zero[C] = {};
       host_store<W, C>(cols, B, i, desc->num_rows, zero);
@@ -143,8 +147,7 @@ void reset_impl(const TetrisDesc* desc, void* cols_, uint64_t* meta, const uint8
     int piece;
     if (stream) {
       int cur = cursor[i];
-      int64_t r0 = cur < stream_len ? cur : stream_len - 1;
-      piece = stream[r0 * B + i];
+      piece = stream[(int64_t)cur * B + i];
       cursor[i] = cur + 1;
     } else {
       piece = tet::bag_draw(bag, desc->n_pieces, tet::hash_env(key, (uint32_t)(env_offset + i)) >> 16);
@@ -297,6 +300,33 @@ int tetris_host_step_call_run(void* call_, const int32_t* action, uint64_t step_
                           c.seed, step_idx, c.env_offset, c.B, unused);
 }
 
+// the step + the payload of the done gather (done bitmask word per 64 envs, counter slots as of this step)
+int tetris_host_step_call_run_gather(void* call_, const int32_t* action, uint64_t step_idx, uint64_t* done_bits,
+                                     uint32_t* status_snapshot, void* unused) {
+  HostStepCall c;
+  memcpy(&c, call_, sizeof(c));
+  const int rc = tetris_host_step_call_run(call_, action, step_idx, unused);
+  if (rc) return rc;
+  const int64_t n_words = (c.B + 63) / 64;
+  if (done_bits) {
+    for (int64_t wv = 0; wv < n_words; ++wv) done_bits[wv] = 0;
+    for (int64_t i = 0; i < c.B; ++i)
+      if (c.done[i]) done_bits[i >> 6] |= 1ull << (i & 63);
+  }
+  if (status_snapshot && c.status) memcpy(status_snapshot, c.status, (size_t)n_words * 16);
+  return 0;
+}
+int tetris_host_stream_link(void* a, void* b) {
+  (void)a;
+  (void)b;
+  return 0;
+}
+const char* tetris_host_source_hash(void) { return "harness"; }
+const char* tetris_host_error_string(int code) {
+  const char* own = tet::error_text(code);
+  return own ? own : "unknown error";
+}
+
 int tetris_host_step_call_run_counted(void* call_, const int32_t* action, const uint64_t* step_counter, uint32_t step_rel,
                                       void* unused) {
   return tetris_host_step_call_run(call_, action, *step_counter + step_rel, unused);
@@ -316,12 +346,12 @@ int tetris_host_counter_add(uint64_t* counter, uint64_t n, void* unused) {
 
 int tetris_host_reset(const TetrisDesc* desc, void* cols, uint64_t* meta, const uint8_t* reset_mask,
                       uint8_t* piece_out, uint8_t* n_valid_out, const uint8_t* stream, int32_t* cursor,
-                      int64_t stream_len, int32_t init_bag, uint64_t seed, uint64_t step_idx, int64_t env_offset,
-                      int64_t B, void* unused) {
+                      int64_t stream_len, uint32_t* status, int32_t init_bag, uint64_t seed, uint64_t step_idx,
+                      int64_t env_offset, int64_t B, void* unused) {
   (void)unused;
   return dispatch(desc, [&](auto w, auto c) {
     reset_impl<decltype(w), decltype(c)::value>(desc, cols, meta, reset_mask, piece_out, n_valid_out, stream, cursor,
-                                                stream_len, init_bag, seed, step_idx, env_offset, B);
+                                                stream_len, status, init_bag, seed, step_idx, env_offset, B);
   });
 }
 
@@ -394,8 +424,8 @@ int tetris_host_policy_greedy(const TetrisDesc* desc, const void* cols_, const u
 }
 
 int tetris_host_rollouts(const TetrisDesc* desc, const void* cols_, const uint64_t* meta, double* returns,
-                         int32_t length, int32_t n, int32_t policy, const float* weights, uint64_t seed,
-                         uint64_t step_idx, int64_t env_offset, int64_t B, void* unused) {
+                         int32_t length, int32_t n, int32_t policy, const float* weights, const uint8_t* pieces,
+                         uint64_t seed, uint64_t step_idx, int64_t env_offset, int64_t B, void* unused) {
   (void)unused;
   return dispatch(desc, [&](auto wt, auto ct) {
     using W = decltype(wt);
@@ -419,8 +449,10 @@ int tetris_host_rollouts(const TetrisDesc* desc, const void* cols_, const uint64
             const uint64_t uid = ((uint64_t)(env_offset + i) * (uint64_t)a_max + (uint64_t)a0) * (uint64_t)n + r;
             const uint32_t key0 = tet::mix32(key ^ ((uint32_t)(uid >> 32) * 0x9E3779B1u));
             W scratch[C];
+            const uint64_t fed = ((uint64_t)(i * a_max + a0) * (uint64_t)n + (uint64_t)r) * (uint64_t)length;
             sum += tet::rollout_env<W, C>(col, meta[i], a0, length, policy, w, tab, kAfterLut, scratch, 1,
-                                          desc->num_rows, desc->n_pieces, key0, (uint32_t)uid);
+                                          desc->num_rows, desc->n_pieces, key0, (uint32_t)uid,
+                                          pieces ? pieces + fed : nullptr);
           }
           mean = (double)sum / (double)n;
         }

@@ -598,6 +598,44 @@ def replay_stream_exhaustion(device, B=70):
     assert env.stats()["invalid"] == 0
     env.step(torch.zeros(B, dtype=torch.int32))
     assert env.stats()["invalid"] == B
+    # a reset past the end of the stream is reported the same way (it consumes one row): untouched, counted
+    before = (env.cols.clone(), env.meta.clone(), env._cursor.clone())
+    env.reset()
+    assert env.stats()["invalid"] == 2 * B
+    assert torch.equal(env.cols, before[0]) and torch.equal(env.meta, before[1]) and torch.equal(env._cursor, before[2])
+    half = torch.arange(B, device=env.device) % 2 == 0
+    env._cursor[half] = 3  # these envs still have rows left
+    env.reset()
+    assert env.stats()["invalid"] == 2 * B + int((~half).sum())
+    assert not env.boards()[half].any() and torch.equal(env._cursor[half], torch.full_like(env._cursor[half], 4))
+    assert torch.equal(env.cols.clone().view(-1), env.cols.view(-1)) and torch.equal(env.meta[~half], before[1][~half])
+
+
+def gather_payload_from_the_step(device, B=64 * 37 + 11):
+    """tetris_hip_step_call_run_gather: the done bitmask and the counter snapshot the step kernel writes from
+    its epilogue equal what the separate kernels produce (pack_done_bits(done), the live counter slots) at that
+    step, and later steps do not touch them."""
+    from tetris_amd import VecTetris
+    from tetris_amd.distributed import pack_done_bits, unpack_done_bits
+    for auto in (True, False):
+        env = VecTetris(10, 20, B, device=device, auto_reset=auto, seed=3)
+        pl = [env.gather_payload(), env.gather_payload()]
+        seen_done = 0
+        for t in range(90):
+            p = pl[t & 1]
+            env.step(gather=p) if t % 3 else env.step(env.random_actions().clone(), gather=p)
+            want_bits = pack_done_bits(env.done)
+            assert torch.equal(p["done_bits"][:want_bits.numel()], want_bits), t
+            assert torch.equal(unpack_done_bits(p["done_bits"], B), env.done)
+            assert torch.equal(p["counters"], env.status.view(-1, 4))
+            seen_done += int(env.done.sum())
+            snap = (p["done_bits"].clone(), p["counters"].clone())
+            env.step()  # a plain step in between leaves the payload alone
+            assert torch.equal(p["done_bits"], snap[0]) and torch.equal(p["counters"], snap[1])
+            assert not torch.equal(p["counters"], env.status.view(-1, 4))
+        assert seen_done > 0
+        if auto:
+            env.check()
 
 
 def device_bag_properties(device, B=1 << 20, steps=48):
@@ -678,6 +716,34 @@ def rollouts_pinned_to_reference(device, orc, golden_dir):
             np.testing.assert_array_equal(np.isnan(got), np.isnan(want[:, :env.a_max]))
             np.testing.assert_array_equal(np.nan_to_num(got, nan=9.0), np.nan_to_num(want[:, :env.a_max], nan=9.0))
         assert (want == -1).any() and (want < -1).any()
+
+
+def rollouts_fed_pieces(device, orc, golden_dir):
+    """g9: perform_rollouts on MULTI-piece sets (game.py:129-160) -- returns recorded from the reference
+    together with the piece its sampler handed out at every rollout step (the global bag advances across
+    rollouts) -- reproduced by tetris_hip_rollouts with those pieces fed in: mean of the n returns per first
+    action, -1 on death, NaN beyond n_valid."""
+    from tetris_amd import VecTetris
+    g = np.load(os.path.join(golden_dir, "g9_rollouts_fed.npz"))
+    w = [float(x) for x in g["weights"]]
+    for tag, pieces in (("default_9", "default"), ("standard7_11", STANDARD7)):
+        R, length, n = int(g[tag + "_rows"]), int(g[tag + "_length"]), int(g[tag + "_n"])
+        boards, want = g[tag + "_boards"], g[tag + "_returns"]
+        env = VecTetris(10, R, len(boards), device=device, pieces=pieces, auto_reset=False, seed=0)
+        env.set_boards(orc.cols_to_cells(boards, R + 4), piece=g[tag + "_piece"].astype(np.int64))
+        fed = g[tag + "_fed"][:, :env.a_max]
+        got = env.rollouts(length=length, n=n, policy="greedy", weights=w, pieces=fed).cpu().numpy()
+        np.testing.assert_array_equal(np.isnan(got), np.isnan(want[:, :env.a_max]))
+        np.testing.assert_array_equal(np.nan_to_num(got, nan=9.0), np.nan_to_num(want[:, :env.a_max], nan=9.0))
+        v = want[~np.isnan(want)]
+        assert (v == -1).any() and (v < -1).any()  # deaths and full runs
+        if tag == "standard7_11":
+            assert (v != np.round(v)).any()  # a mean over rollouts that fared differently (the bag moved on)
+        # the fed pieces matter: with the env's own bag fork the returns differ somewhere
+        own = env.rollouts(length=length, n=n, policy="greedy", weights=w).cpu().numpy()
+        assert not np.array_equal(np.nan_to_num(own, nan=9.0), np.nan_to_num(got, nan=9.0))
+        with pytest.raises(ValueError):
+            env.rollouts(length=length, n=n + 1, policy="greedy", weights=w, pieces=fed)
 
 
 def cfg3_full_size_bit_exact(device, orc, B=1 << 20, steps=48, R=20, pieces="default", board_every=12):

@@ -113,3 +113,6 @@ def test_stale_traffic_profile_is_not_quoted(tmp_path, monkeypatch):
     assert bench.load_traffic(10, 40, "default", 1 << 20) is None       # other workload
     (tmp_path / "tetris_amd" / "csrc" / "k.hip").write_text("// v2\n")  # the kernels changed
     assert bench.load_traffic(10, 20, "default", 1 << 20) is None
+    # what counts is the hash compiled into the LOADED library
+    assert bench.load_traffic(10, 20, "default", 1 << 20, lib_hash=prof["csrc_hash"]) == 123.0
+    assert bench.load_traffic(10, 20, "default", 1 << 20, lib_hash="0123456789abcdef") is None

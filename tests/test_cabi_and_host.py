@@ -50,7 +50,7 @@ def test_desc_init_and_argument_errors(hip_lib):
     # NULL pointers / bad batch are refused before anything is launched (no GPU needed)
     assert hip_lib.step(ctypes.byref(d), None, None, None, None, None, None, 0, None, None, None, None, None, None,
                         None, 0, 0, 0, 0, 16, None) == -1
-    assert hip_lib.reset(ctypes.byref(d), None, None, None, None, None, None, None, 0, 1, 0, 0, 0, 16, None) == -1
+    assert hip_lib.reset(ctypes.byref(d), None, None, None, None, None, None, None, 0, None, 1, 0, 0, 0, 16, None) == -1
     z = _lib.TetrisDesc()
     assert hip_lib.refresh(ctypes.byref(z), None, None, None, 16, None) == -2  # uninitialised descriptor
     assert "NULL" in hip_lib.error_string(-1)

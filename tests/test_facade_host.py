@@ -32,3 +32,7 @@ def test_rollout_script(host_backend, golden_dir):
 
 def test_render_strings(host_backend, golden_dir):
     fc.render_strings("cpu", golden_dir)
+
+
+def test_unsupported_widths_are_refused(host_backend):
+    fc.unsupported_widths_are_refused("cpu")

@@ -204,3 +204,16 @@ def test_bench_rccl_path_one_rank():
     assert out["ranks"]["per_rank"][0]["envs"] == [0, 1 << 20]
     assert out["done_gather"]["bitmask_gathers_in_timed_region"] == 1 and out["done_gather"]["ms_per_gather"] > 0
     assert out["episodes"] > 0 and out["n_gpus"] == 1 and out["value"] > 1e9
+
+
+def test_gather_payload_from_the_step():
+    pc.gather_payload_from_the_step(DEV)
+
+
+def test_rollouts_fed_pieces(orc, golden_dir):
+    pc.rollouts_fed_pieces(DEV, orc, golden_dir)
+
+
+def test_unsupported_widths_are_refused():
+    import facade_cases as fc
+    fc.unsupported_widths_are_refused(DEV)

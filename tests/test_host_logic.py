@@ -111,3 +111,11 @@ def test_graph_steps_equal_steps(host_backend):
 
 def test_done_bit_packing(host_backend):
     pc.done_bit_packing(DEV)
+
+
+def test_gather_payload_from_the_step(host_backend):
+    pc.gather_payload_from_the_step(DEV, B=64 * 5 + 11)
+
+
+def test_rollouts_fed_pieces(host_backend, orc, golden_dir):
+    pc.rollouts_fed_pieces(DEV, orc, golden_dir)

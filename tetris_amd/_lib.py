@@ -9,7 +9,7 @@ import os
 from . import build as _build
 
 MAX_PIECES = 12
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class TetrisDesc(ctypes.Structure):
@@ -43,13 +43,15 @@ SIGNATURES = {
     "tetris_hip_status_words": [_i64],
     "tetris_hip_n_planes": [_dp],
     "tetris_hip_board_words": [_dp, _i64],
-    "tetris_hip_reset": [_dp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _u64, _u64, _i64, _i64, _vp],
+    "tetris_hip_reset": [_dp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i32, _u64, _u64, _i64, _i64, _vp],
     "tetris_hip_step": [_dp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _u64, _u64,
                         _i64, _i64, _vp],
     "tetris_hip_step_call_size": [],
     "tetris_hip_step_call_init": [_vp, _dp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _u64,
                                   _i64, _i64],
     "tetris_hip_step_call_run": [_vp, _vp, _u64, _vp],
+    "tetris_hip_step_call_run_gather": [_vp, _vp, _u64, _vp, _vp, _vp],
+    "tetris_hip_stream_link": [_vp, _vp],
     "tetris_hip_step_call_run_counted": [_vp, _vp, _vp, ctypes.c_uint32, _vp],
     "tetris_hip_counter_add": [_vp, _u64, _vp],
     "tetris_hip_pack_done_bits": [_vp, _vp, _i64, _vp],
@@ -57,14 +59,14 @@ SIGNATURES = {
                              _i64, _i64, _vp],
     "tetris_hip_afterstates": [_dp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp],
     "tetris_hip_policy_greedy": [_dp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
-    "tetris_hip_rollouts": [_dp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _u64, _u64, _i64, _i64, _vp],
+    "tetris_hip_rollouts": [_dp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _u64, _u64, _i64, _i64, _vp],
     "tetris_hip_policy_random": [_vp, _vp, _u64, _u64, _i64, _i64, _vp],
     "tetris_hip_numpy_bag_stream": [_vp, _i32, _i64, _vp, _i64, _vp],
     "tetris_hip_decode": [_dp, _vp, _vp, _vp, _i64, _vp],
     "tetris_hip_encode": [_dp, _vp, _vp, _i64, _vp],
     "tetris_hip_refresh": [_dp, _vp, _vp, _vp, _i64, _vp],
 }
-EXPORTS = list(SIGNATURES) + ["tetris_hip_error_string"]
+EXPORTS = list(SIGNATURES) + ["tetris_hip_error_string", "tetris_hip_source_hash"]
 
 
 class _Binding:
@@ -87,6 +89,15 @@ class _Binding:
             self._errstr.restype = ctypes.c_char_p
         else:
             self._errstr = None
+        self._srchash = None
+        if hasattr(cdll, prefix + "source_hash"):
+            self._srchash = getattr(cdll, prefix + "source_hash")
+            self._srchash.argtypes = []
+            self._srchash.restype = ctypes.c_char_p
+
+    def source_hash(self):
+        """Hash of the kernel sources the loaded library was built from ("unknown" for ad-hoc builds)."""
+        return self._srchash().decode() if self._srchash is not None else "unknown"
 
     def error_string(self, code):
         if self._errstr is not None:

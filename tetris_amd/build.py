@@ -17,6 +17,19 @@ def _hipcc():
     raise RuntimeError("hipcc not found: libtetris_hip.so cannot be built (set HIPCC=/path/to/hipcc)")
 
 
+def source_hash():
+    """Content hash of the kernel sources (what bench.py calls csrc_hash): compiled into the library as
+    tetris_hip_source_hash() so that a measurement can be tied to the binary that produced it."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(_CSRC)):
+        if name.endswith((".hip", ".hpp", ".inc", ".h")):
+            h.update(name.encode())
+            with open(os.path.join(_CSRC, name), "rb") as f:
+                h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def is_stale():
     if not os.path.exists(SO_PATH):
         return True
@@ -43,7 +56,8 @@ def build_hip(force=False, verbose=False, jobs=None):
     jobs = jobs or max(1, min(len(_COLUMNS) + 1, (os.cpu_count() or 2)))
     tmp = "%s.%d.tmp" % (SO_PATH, os.getpid())  # build aside, then rename: never a half-written .so
     with tempfile.TemporaryDirectory(prefix="tetris_build_") as d:
-        units = [("main", ["-DTET_SPLIT_MAIN"])] + [("c%d" % c, ["-DTET_PART=%d" % c]) for c in _COLUMNS]
+        units = [("main", ["-DTET_SPLIT_MAIN", '-DTET_SRC_HASH="%s"' % source_hash()])] + \
+                [("c%d" % c, ["-DTET_PART=%d" % c]) for c in _COLUMNS]
         objs, running = [], []
         pending = list(units)
 

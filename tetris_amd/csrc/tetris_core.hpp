@@ -915,6 +915,7 @@ TET_HD void afterstates_env(const W (&col)[C], uint64_t meta, const SetTable& ta
           a_ex &= col[i];
           o_ex |= HO[i];
         }
+
 #pragma unroll
       for (int oi = 0; oi < 2; ++oi) {
         const int k = 2 * L + oi;
@@ -1144,11 +1145,12 @@ TET_HD void env_step(W (&col)[C], uint64_t& meta, int action, bool use_policy, c
 // returns -1 if the env is already over, dies on the first step or on any later one, else the
 // sum of the rewards of steps 2..length (game.py:133-146; the first reward is not counted).
 // policy 0: uniform random valid action; 1: greedy on the linear fitness `w` (first maximum).
-// Pieces come from a fork of the env's bag driven by hash(key0 + t, uid); the env is untouched.
+// Pieces come from a fork of the env's bag driven by hash(key0 + t, uid), or from `fed` (one list
+// index per step: what the reference's sampler handed out in a recorded run); the env is untouched.
 template <typename W, int C, int NCH = 0>
 TET_HD int rollout_env(const W (&col0)[C], uint64_t meta0, int a0, int length, int policy, const float (&w)[8],
                        const SetTable& tab, const uint8_t* hole_lut, W* scratch, int sstride, int R, int n_pieces,
-                       uint32_t key0, uint32_t uid) {
+                       uint32_t key0, uint32_t uid, const uint8_t* fed = nullptr) {
   W col[C];
 #pragma unroll
   for (int i = 0; i < C; ++i) col[i] = col0[i];
@@ -1192,7 +1194,9 @@ TET_HD int rollout_env(const W (&col0)[C], uint64_t meta0, int a0, int length, i
       }
     }
     StepOut out;
-    env_step<W, C, NCH, 12, true>(col, meta, action, use_policy, tab, hole_lut, scratch, sstride, cfg, uid, -1, -1, out);
+    // fed: the piece each step draws comes from the caller (a recorded reference run) instead of the bag fork
+    env_step<W, C, NCH, 12, true>(col, meta, action, use_policy, tab, hole_lut, scratch, sstride, cfg, uid,
+                                  fed ? (int)fed[t] : -1, -1, out);
     if (out.done || out.invalid) return -1;  // game.py:135-138,143-145
     if (t > 0) ret += out.reward;
   }

@@ -241,9 +241,10 @@ __device__ __forceinline__ void load_inputs(const StepParams& p, uint32_t i, Ste
 // evening that out with s_setprio recovers the tie, no more (profiles/r02_experiments/).
 // NCH = number of 12-row chunks of the stored board, fixed at compile time for the common
 // geometries (2: up to 24 stored rows, e.g. 10x20; 4: up to 48, e.g. 10x40), 0 = decide from R.
-template <typename W, int C, int NCH, int CR>
-__global__ __launch_bounds__(step_block<W>(), (step_waves<W, CR>())) void step_kernel(const StepParams p) {
-  constexpr int kBlock = step_block<W>();  // shadows the file-wide tile size inside this kernel
+// BLK: envs per workgroup (step_block<W>(), or 256 for the small-batch variant of the headline geometry).
+template <typename W, int C, int NCH, int CR, int BLK = step_block<W>()>
+__global__ __launch_bounds__(BLK, (step_waves<W, CR>())) void step_kernel(const StepParams p) {
+  constexpr int kBlock = BLK;  // shadows the file-wide tile size inside this kernel
   __shared__ StepLds<W, C, kBlock, CR> lds;
   SetTable& tab = lds.tab;
   uint8_t* const hole_lut = lds.lut;
@@ -289,7 +290,7 @@ __global__ __launch_bounds__(step_block<W>(), (step_waves<W, CR>())) void step_k
     cfg.key_step = tet::hash_key(p.seed, idx * 4u + 0u);
     cfg.key_policy = tet::hash_key(p.seed, idx * 4u + 3u);
   }
-  int invalid = 0, done = 0, lines = 0;
+  int invalid = 0, done = 0, lines = 0, done_flag = 0;
   if (live) {
     tet::StepOut out;
     tet::env_step<W, C, NCH, CR>(in.col, in.meta, in.exhausted ? -1 : in.action, p.action == nullptr && !in.exhausted,
@@ -309,6 +310,7 @@ __global__ __launch_bounds__(step_block<W>(), (step_waves<W, CR>())) void step_k
       lines = out.lines;
       if (p.stream) p.cursor[i] = in.cursor + 1 + ((out.done && cfg.auto_reset) ? 1 : 0);
     }
+    done_flag = out.done;  // what the done array holds (an env that was already over reports done again)
     st_off(p.reward, i * 4u, (int32_t)out.reward);
     st_off(p.done, i, (uint8_t)out.done);
     st_off(p.lines, i, (uint8_t)out.lines);
@@ -317,9 +319,9 @@ __global__ __launch_bounds__(step_block<W>(), (step_waves<W, CR>())) void step_k
     if (p.action_out) st_off(p.action_out, i * 4u, (int32_t)out.action);
   }
   if (p.status || p.done_bits) {
-    const unsigned long long done_mask = __ballot(done != 0);
+    const unsigned long long done_mask = __ballot(done_flag != 0);  // == tetris_hip_pack_done_bits(done)
     const unsigned n_inv = wave_sum(1, invalid);
-    const unsigned n_done = (unsigned)__popcll(done_mask);
+    const unsigned n_done = wave_sum(1, done);
     const unsigned n_lines = wave_sum(3, lines);
     const unsigned n_steps = wave_sum(1, (live && !invalid) ? 1 : 0);
     if ((threadIdx.x & 63) == 0) {
@@ -465,6 +467,7 @@ __global__ __launch_bounds__(step_block<W>(), (POLICY == 0 ? step_waves<W, CR>()
 struct ResetParams {
   void* cols;
   uint64_t* meta;
+  uint32_t* status;        // per-wave counters or NULL: an env whose replay stream is exhausted is counted as invalid
   const uint8_t* reset_mask;
   uint8_t* piece_out;
   uint8_t* n_valid_out;
@@ -485,17 +488,23 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const ResetParams p) {
   __shared__ SetTable tab;
   stage_table(tab, p.tab);
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (i >= p.B) return;
-  if (p.reset_mask && !p.reset_mask[i]) return;
+  const bool mine = i < p.B && !(p.reset_mask && !p.reset_mask[i]);
+  // replay mode: a reset consumes one stream row; an env whose cursor is at or past the end is left
+  // untouched and counted as invalid (as tetris_hip_step does), never continued on the last row
+  const int cur = (mine && p.stream) ? p.cursor[i] : 0;
+  const bool exhausted = mine && p.stream && (cur < 0 || cur >= p.stream_len);
+  if (p.status) {
+    const unsigned n_bad = (unsigned)__popcll(__ballot(exhausted));
+    if ((threadIdx.x & 63) == 0 && n_bad) p.status[(i >> 6) * 4 + TETRIS_STATUS_INVALID] += n_bad;
+  }
+  if (!mine || exhausted) return;
   W* cols = static_cast<W*>(p.cols);
 #pragma unroll
   for (int q = 0; q < tet::n_planes(C, PACK); ++q) cols[tet::plane_index(i, q, tet::n_planes(C, PACK))] = 0;  // game.py:55-58
   uint32_t bag = p.init_bag ? 0u : tet::meta_bag(p.meta[i]);
   int piece;
   if (p.stream) {
-    int cur = p.cursor[i];
-    int64_t r0 = cur < p.stream_len ? cur : p.stream_len - 1;
-    piece = p.stream[r0 * p.B + i];
+    piece = p.stream[(int64_t)cur * p.B + i];
     p.cursor[i] = cur + 1;
   } else {
     piece = tet::bag_draw(bag, p.n_pieces, tet::hash_env(p.key, (uint32_t)(p.env_offset + i)) >> 16);  // game.py:60
@@ -705,6 +714,7 @@ struct RolloutParams {
   int32_t n;
   int32_t policy;
   uint32_t key;
+  const uint8_t* pieces;  // NULL, or uint8 [B][a_max][n][length]: the piece every step of every rollout draws
   float w[8];
   SetTable tab;
 };
@@ -737,8 +747,10 @@ __global__ __launch_bounds__(kRolloutBlock, (after_waves<W>(TET_STEP_GREEDY_WAVE
     for (int r = 0; r < p.n; ++r) {
       const uint64_t uid = ((uint64_t)(p.env_offset + i) * (uint64_t)p.a_max + (uint64_t)a0) * (uint64_t)p.n + r;
       const uint32_t key0 = tet::mix32(p.key ^ ((uint32_t)(uid >> 32) * 0x9E3779B1u));
+      const uint64_t fed = ((uint64_t)(i * p.a_max + a0) * (uint64_t)p.n + (uint64_t)r) * (uint64_t)p.length;
       sum += tet::rollout_env<W, C, NCH>(col, meta, a0, p.length, p.policy, p.w, tab, hole_lut,
-                                    &lane_cols[0][threadIdx.x], kBlock, p.R, p.n_pieces, key0, (uint32_t)uid);
+                                    &lane_cols[0][threadIdx.x], kBlock, p.R, p.n_pieces, key0, (uint32_t)uid,
+                                    p.pieces ? p.pieces + fed : nullptr);
     }
     mean = (double)sum / (double)p.n;
   }
@@ -852,6 +864,7 @@ __global__ __launch_bounds__(kBlock) void encode_kernel(const int8_t* __restrict
 
 inline dim3 grid_for(int64_t B) { return dim3((unsigned)((B + kBlock - 1) / kBlock)); }
 inline dim3 rollout_grid(int64_t n) { return dim3((unsigned)((n + kRolloutBlock - 1) / kRolloutBlock)); }
+constexpr uint32_t kSmallBatch = 262144;
 template <typename W>
 inline dim3 step_grid(int64_t B) { return dim3((unsigned)((B + step_block<W>() - 1) / step_block<W>())); }
 
@@ -881,9 +894,15 @@ struct LaunchStep {
     constexpr int N = packed_chunks<W>();
     if (!packed_geometry<W>(p.cfg.R))
       hipLaunchKernelGGL((step_kernel<W, C, 0, 12>), step_grid<W>(p.B), dim3(step_block<W>()), 0, s, p);
-    else if (p.cfg.R <= 10 * N && TET_LUT10)
-      hipLaunchKernelGGL((step_kernel<W, C, N, 10>), step_grid<W>(p.B), dim3(step_block<W>()), 0, s, p);
-    else
+    else if (p.cfg.R <= 10 * N && TET_LUT10) {
+      // small batches (at most 4 waves per SIMD): 256-env tiles put a workgroup on every CU from 65,536 envs
+      // on and shorten its table staging: 6.75 us against 7.24 us per step at 65,536 envs, 1 % slower at
+      // 1 Mi envs and beyond (profiles/r03_experiments/small_batch_variants.txt)
+      if (step_block<W>() > 256 && p.B <= kSmallBatch)
+        hipLaunchKernelGGL((step_kernel<W, C, N, 10, 256>), dim3((p.B + 255) / 256), dim3(256), 0, s, p);
+      else
+        hipLaunchKernelGGL((step_kernel<W, C, N, 10>), step_grid<W>(p.B), dim3(step_block<W>()), 0, s, p);
+    } else
       hipLaunchKernelGGL((step_kernel<W, C, N, 12>), step_grid<W>(p.B), dim3(step_block<W>()), 0, s, p);
   }
 };
@@ -1029,18 +1048,8 @@ int tetris_debug_read_stamps(uint64_t* dst, int n_wgs) {
 #endif
 
 const char* tetris_hip_error_string(int code) {
-  switch (code) {
-    case TETRIS_OK: return "ok";
-    case TETRIS_E_NULL: return "required pointer is NULL";
-    case TETRIS_E_DESC: return "descriptor not initialised by tetris_hip_desc_init or inconsistent";
-    case TETRIS_E_COLUMNS: return "num_columns not compiled into libtetris_hip";
-    case TETRIS_E_ROWS: return "num_rows outside [4, 59]";
-    case TETRIS_E_PIECES: return "bad piece list";
-    case TETRIS_E_BATCH: return "batch size must be positive";
-    case TETRIS_E_STREAM: return "replay stream needs cursor and stream_len > 0";
-    case TETRIS_E_STRIDE: return "afterstate strides must be multiples of 4 floats and >= 8";
-    default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown error";
-  }
+  const char* own = tet::error_text(code);
+  return own ? own : (code > 0 ? hipGetErrorString((hipError_t)code) : "unknown error");
 }
 
 int tetris_hip_supported_columns(int32_t* out, int cap) {
@@ -1082,7 +1091,7 @@ int tetris_hip_desc_init(TetrisDesc* desc, int32_t num_columns, int32_t num_rows
 
 int tetris_hip_reset(const TetrisDesc* desc, void* cols, uint64_t* meta, const uint8_t* reset_mask,
                      uint8_t* piece_out, uint8_t* n_valid_out, const uint8_t* stream, int32_t* cursor,
-                     int64_t stream_len, int32_t init_bag, uint64_t seed, uint64_t step_idx,
+                     int64_t stream_len, uint32_t* status, int32_t init_bag, uint64_t seed, uint64_t step_idx,
                      int64_t env_offset, int64_t B, void* hip_stream) {
   int rc = check_desc(desc);
   if (rc) return rc;
@@ -1092,6 +1101,7 @@ int tetris_hip_reset(const TetrisDesc* desc, void* cols, uint64_t* meta, const u
   ResetParams p{};
   p.cols = cols;
   p.meta = meta;
+  p.status = status;
   p.reset_mask = reset_mask;
   p.piece_out = piece_out;
   p.n_valid_out = n_valid_out;
@@ -1230,6 +1240,40 @@ int tetris_hip_step_call_run(void* call_, const int32_t* action, uint64_t step_i
   return dispatch<LaunchStep>(&call->desc, p, (hipStream_t)hip_stream);
 }
 
+int tetris_hip_step_call_run_gather(void* call_, const int32_t* action, uint64_t step_idx, uint64_t* done_bits,
+                                    uint32_t* status_snapshot, void* hip_stream) {
+  TetrisStepCall* call = static_cast<TetrisStepCall*>(call_);
+  if (!call) return TETRIS_E_NULL;
+  if (call->magic != kStepCallMagic) return TETRIS_E_DESC;
+  StepParams p = call->p;  // (a copy: the bound call itself stays free of the payload pointers)
+  p.action = action;
+  p.action_out = action ? nullptr : call->action_out;
+  p.cfg.key_step = tet::hash_key(call->seed, step_idx * 4u + 0u);
+  p.cfg.key_policy = tet::hash_key(call->seed, step_idx * 4u + 3u);
+  p.done_bits = reinterpret_cast<unsigned long long*>(done_bits);
+  p.status_snapshot = status_snapshot;
+  return dispatch<LaunchStep>(&call->desc, p, (hipStream_t)hip_stream);
+}
+
+int tetris_hip_stream_link(void* from_stream, void* to_stream) {
+  // `to_stream` waits for everything enqueued on `from_stream` so far.  The event releases to DEVICE scope:
+  // producer and consumer run on the same GPU (the consumer is the RCCL kernel that reads the gather
+  // payload), so the system-scope cache write-back a default event carries is not needed -- that write-back
+  // is what made a recorded event cost the stepping stream tens of microseconds.
+  hipEvent_t ev;
+  hipError_t rc = hipEventCreateWithFlags(&ev, hipEventDisableTiming | hipEventReleaseToDevice);
+  if (rc != hipSuccess) return (int)rc;
+  rc = hipEventRecord(ev, (hipStream_t)from_stream);
+  if (rc == hipSuccess) rc = hipStreamWaitEvent((hipStream_t)to_stream, ev, 0);
+  const hipError_t rc2 = hipEventDestroy(ev);  // (released once the wait has consumed it)
+  return (int)(rc != hipSuccess ? rc : rc2);
+}
+
+#ifndef TET_SRC_HASH
+#define TET_SRC_HASH "unknown"
+#endif
+const char* tetris_hip_source_hash(void) { return TET_SRC_HASH; }
+
 int tetris_hip_step_call_run_counted(void* call_, const int32_t* action, const uint64_t* step_counter, uint32_t step_rel,
                                      void* hip_stream) {
   TetrisStepCall* call = static_cast<TetrisStepCall*>(call_);
@@ -1307,8 +1351,8 @@ int tetris_hip_policy_greedy(const TetrisDesc* desc, const void* cols, const uin
 }
 
 int tetris_hip_rollouts(const TetrisDesc* desc, const void* cols, const uint64_t* meta, double* returns,
-                        int32_t length, int32_t n, int32_t policy, const float* weights, uint64_t seed,
-                        uint64_t step_idx, int64_t env_offset, int64_t B, void* hip_stream) {
+                        int32_t length, int32_t n, int32_t policy, const float* weights, const uint8_t* pieces,
+                        uint64_t seed, uint64_t step_idx, int64_t env_offset, int64_t B, void* hip_stream) {
   int rc = check_desc(desc);
   if (rc) return rc;
   if (!cols || !meta || !returns || (policy == 1 && !weights)) return TETRIS_E_NULL;
@@ -1325,6 +1369,7 @@ int tetris_hip_rollouts(const TetrisDesc* desc, const void* cols, const uint64_t
   p.length = length;
   p.n = n;
   p.policy = policy;
+  p.pieces = pieces;
   p.key = tet::hash_key(seed ^ 0x526F6C6C6F757473ull, step_idx);
   for (int i = 0; i < 8; ++i) p.w[i] = weights ? weights[i] : 0.f;
   build_table(desc, &p.tab);

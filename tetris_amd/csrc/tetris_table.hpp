@@ -118,6 +118,22 @@ inline bool columns_supported(int C) {
   }
 }
 
+// text of the library's own (non-positive) return codes; NULL for anything else
+inline const char* error_text(int code) {
+  switch (code) {
+    case TETRIS_OK: return "ok";
+    case TETRIS_E_NULL: return "required pointer is NULL";
+    case TETRIS_E_DESC: return "descriptor not initialised by tetris_hip_desc_init or inconsistent";
+    case TETRIS_E_COLUMNS: return "num_columns not compiled into libtetris_hip";
+    case TETRIS_E_ROWS: return "num_rows outside [4, 59]";
+    case TETRIS_E_PIECES: return "bad piece list";
+    case TETRIS_E_BATCH: return "batch size must be positive";
+    case TETRIS_E_STREAM: return "replay stream needs cursor and stream_len > 0";
+    case TETRIS_E_STRIDE: return "afterstate strides must be multiples of 4 floats and >= 8";
+    default: return nullptr;
+  }
+}
+
 inline int check_desc(const TetrisDesc* d) {
   if (!d) return TETRIS_E_NULL;
   if (d->abi_version != TETRIS_HIP_ABI_VERSION) return TETRIS_E_DESC;

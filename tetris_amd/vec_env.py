@@ -205,8 +205,8 @@ class VecTetris:
                 raise ValueError("mask must be [batch_size]")
         s, c, n = self._stream_args()
         rc = self._lib.reset(ctypes.byref(self.desc), _ptr(self.cols), _ptr(self.meta), _ptr(m), _ptr(self.piece),
-                             _ptr(self.n_valid), s, c, n, int(bool(init_bag)), self.seed, self.step_idx,
-                             self.env_offset, self.batch_size, self._hip_stream())
+                             _ptr(self.n_valid), s, c, n, _ptr(self.status), int(bool(init_bag)), self.seed,
+                             self.step_idx, self.env_offset, self.batch_size, self._hip_stream())
         self._lib.check(rc, "tetris_hip_reset")
 
     # -- Tetris.get_after_states (game.py:67-80) --------------------------------------
@@ -240,10 +240,20 @@ class VecTetris:
         return view(self._feats), self._nv_after
 
     # -- Tetris.step (game.py:82-92) ------------------------------------------------------
-    def step(self, action=None):
+    def gather_payload(self):
+        """Buffers for one done/reset gather (``step(..., gather=payload)``): ``done_bits`` uint8
+        [8 * ceil(B / 64)] -- the done bitmask, bit i % 8 of byte i // 8 -- and ``counters`` int32
+        [n_waves, 4] -- the per-wave (invalid, episodes, lines, steps) slots as of that step.  The step
+        kernel writes both from its epilogue; nothing else touches them, so a collective can read them
+        on another stream (``tetris_hip_stream_link``) while the env keeps stepping."""
+        return dict(done_bits=torch.zeros(((self.batch_size + 63) // 64) * 8, dtype=torch.uint8, device=self.device),
+                    counters=torch.zeros_like(self.status).view(-1, 4))
+
+    def step(self, action=None, gather=None):
         """``action`` [B] = index into each env's non-terminal placements; ``None`` = every env
         plays a uniform random valid action drawn inside the kernel (readable afterwards in
-        ``self.action``; identical to ``step(random_actions())``).
+        ``self.action``; identical to ``step(random_actions())``).  ``gather``: a
+        :meth:`gather_payload` this step fills in (done bitmask + counter snapshot).
 
         Returns ``(obs [B,8] f32, reward [B] i32, done [B] bool, lines [B] u8)``.
         Out-of-range actions leave that env untouched and are counted; call
@@ -265,7 +275,11 @@ class VecTetris:
             stream = self._raw_stream(self.device.index)
         else:
             stream = self._hip_stream()
-        rc = self._lib.step_call_run(call, None if a is None else a.data_ptr(), self.step_idx, stream)
+        if gather is None:
+            rc = self._lib.step_call_run(call, None if a is None else a.data_ptr(), self.step_idx, stream)
+        else:
+            rc = self._lib.step_call_run_gather(call, None if a is None else a.data_ptr(), self.step_idx,
+                                                gather["done_bits"].data_ptr(), gather["counters"].data_ptr(), stream)
         if rc:
             self._lib.check(rc, "tetris_hip_step_call_run")
         self.step_idx += 1
@@ -366,16 +380,26 @@ class VecTetris:
             return self._best_action, self._best_value, fa
         return self._best_action, self._best_value
 
-    def rollouts(self, length=5, n=5, policy="random", weights=None):
+    def rollouts(self, length=5, n=5, policy="random", weights=None, pieces=None):
         """Tetris.perform_rollouts (game.py:150-160) for every env and every valid first action:
         ``returns float64 [B, a_max]`` = mean rollout return over ``n`` rollouts of ``length`` steps
         (NaN where the action does not exist).  ``policy`` = "random" or "greedy" (linear fitness
-        on ``weights``, default the BCTS weights of game.py:111-118).  The envs are not modified."""
+        on ``weights``, default the BCTS weights of game.py:111-118).  ``pieces`` (optional uint8
+        ``[B, a_max, n, length]``): the list index every step of every rollout draws -- a recorded run
+        of the reference's sampler; without it every rollout draws from its own fork of the env's bag.
+        The envs are not modified."""
         pol = {"random": 0, "greedy": 1}[policy]
         w = (ctypes.c_float * 8)(*(self.BCTS_WEIGHTS if weights is None else [float(x) for x in weights]))
         out = torch.empty((self.batch_size, self.a_max), dtype=torch.float64, device=self.device)
+        fed = None
+        if pieces is not None:
+            fed = torch.as_tensor(pieces, dtype=torch.uint8).to(self.device).contiguous()
+            if tuple(fed.shape) != (self.batch_size, self.a_max, int(n), int(length)):
+                raise ValueError("pieces must be [batch_size, a_max, n, length]")
+            if int(fed.max()) >= len(self.piece_names):
+                raise ValueError("pieces holds an index outside the piece list")
         rc = self._lib.rollouts(ctypes.byref(self.desc), _ptr(self.cols), _ptr(self.meta), _ptr(out), int(length),
-                                int(n), pol, w, self.seed, self.step_idx, self.env_offset, self.batch_size,
+                                int(n), pol, w, _ptr(fed), self.seed, self.step_idx, self.env_offset, self.batch_size,
                                 self._hip_stream())
         self._lib.check(rc, "tetris_hip_rollouts")
         return out
