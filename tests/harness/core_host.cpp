@@ -199,9 +199,12 @@ void after_impl(const TetrisDesc* desc, const void* cols_, const uint64_t* meta,
     }
     int nv = tet::popc(valid), na = tet::popc(full);
     bool consistent = true;
-    tet::afterstates_env<W, C, 0>(col, meta[i], tab, kAfterLut, R, [&](bool has, int sk, int sc, float (&f)[8]) {
+    tet::afterstates_env<W, C, 0>(col, meta[i], tab, kAfterLut, R, [&](bool has, int sk, int sc, float (&f)[8], int row_all, int row_valid, bool is_valid) {
           if (!has) return;
       const int s = tet::mask_bit(sk, sc);
+      // (0) the running row indices of the walk against the popcount form
+      consistent = consistent && row_all == tet::row_of_slot<C>(full, sk, sc) && is_valid == (bool)((valid >> s) & 1) &&
+                   (!is_valid || row_valid == tet::row_of_slot<C>(valid, sk, sc));
       // cross-checks (test harness only): (1) the incremental features against the full
       // evaluation of the same placement, (2) the cached mask against the direct terminal test
       const tet::Orient o = tet::unpack_orient(tab.orient[piece][sk].desc);
@@ -405,7 +408,7 @@ int tetris_host_policy_greedy(const TetrisDesc* desc, const void* cols_, const u
         for (int k = 0; k < desc->a_max; ++k) fall[k] = 0.f;
       float best = 0.f;
       int best_row = -1;
-      tet::afterstates_env<W, C, 0>(col, meta[i], tab, kAfterLut, desc->num_rows, [&](bool has, int sk, int sc, float (&f)[8]) {
+      tet::afterstates_env<W, C, 0>(col, meta[i], tab, kAfterLut, desc->num_rows, [&](bool has, int sk, int sc, float (&f)[8], int, int, bool) {
           if (!has) return;
         const float v = tet::fitness_of(f, w);
         if (fall) fall[tet::row_of_slot<C>(full, sk, sc)] = v;
@@ -496,7 +499,7 @@ int tetris_host_step_many(const TetrisDesc* desc, void* cols_, uint64_t* meta, i
           const uint64_t valid = tet::meta_mask(m);
           float best = 0.f;
           int best_row = -1;
-          tet::afterstates_env<W, C, 0>(col, m, tab, kAfterLut, cfg.R, [&](bool has, int sk, int sc, float (&f)[8]) {
+          tet::afterstates_env<W, C, 0>(col, m, tab, kAfterLut, cfg.R, [&](bool has, int sk, int sc, float (&f)[8], int, int, bool) {
           if (!has) return;
             if ((valid >> tet::mask_bit(sk, sc)) & 1) {
               const float v = tet::fitness_of(f, w);

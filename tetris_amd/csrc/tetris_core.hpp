@@ -832,8 +832,10 @@ TET_HD int stamp_scratch(W (&col)[C], W* scratch, int sstride, int c, uint32_t d
 }
 
 // ---- all afterstates of one env (game.py:67-80) -----------------------------------------
-// emit(has, field k = 2L + o, column c, f[8]) is called for every placement of the current piece
-// with the BCTS features of its afterstate.  On the device the calls are WAVE-UNIFORM: every lane
+// emit(has, field k = 2L + o, column c, f[8], row_all, row_valid, is_valid) is called for every placement
+// of the current piece with the BCTS features of its afterstate; row_all = its index among all placements
+// of the piece, row_valid = among the non-terminal ones (= the action, game.py:69; meaningful when
+// is_valid) -- running counts here, because the walk follows the reference's order.  On the device the calls are WAVE-UNIFORM: every lane
 // of the wavefront reaches every call (so the caller may cooperate across lanes, e.g. to merge
 // stores) and `has` tells whether this lane's env really has the placement (f is garbage
 // otherwise).  Slots are walked in the reference's enumeration order (loop L, column c,
@@ -854,9 +856,11 @@ TET_HD int stamp_scratch(W (&col)[C], W* scratch, int sstride, int c, uint32_t d
 // Rounds 1-2 re-read the hole tables for every footprint column and three byte tables per chunk for
 // the wells: 28 LDS reads per placement with 3-4-way bank conflicts on random indices, on the one LDS
 // pipe four SIMDs share -- that pipe, not the vector ALUs, bounded the walk; this form issues 8-10.
-// (Tried and dropped in round 3: the wells difference from a 4-row window table -- one read per
-// column but twice the vector instructions -- and one lane per (env, column) with LDS-staged
-// contiguous stores: 5-9 x the wave instructions per env.  profiles/r03_experiments/.)
+// (Tried and dropped in round 3, all measured: the wells difference from a 4-row window table -- one read
+// per column but twice the vector instructions; one lane per (env, column) with LDS-staged contiguous
+// stores -- 5-9 x the wave instructions per env; the column loop rolled at run time with the arrays read in
+// GPR-index mode -- a third of the code and 134 VGPRs, but slower at every occupancy.
+// profiles/r03_experiments/.)
 // Placements that complete a row (about 1 %) take the full evaluation afterwards.
 // `lut` is an AfterLut.
 template <typename W, int C, int NCH, typename Emit>
@@ -896,6 +900,8 @@ TET_HD void afterstates_env(const W (&col)[C], uint64_t meta, const SetTable& ta
     }
   }
   uint64_t slow = 0;  // placements that clear lines: evaluated in full below
+  const uint64_t valid = meta_mask(meta) & full;
+  int row_all = 0, row_valid = 0;  // running row indices (the walk is in the reference's order)
 #pragma unroll 1
   for (int L = 0; L < 2; ++L) {
     const uint32_t d0 = tab.orient[piece][2 * L].desc, d1 = tab.orient[piece][2 * L + 1].desc;
@@ -925,6 +931,10 @@ TET_HD void afterstates_env(const W (&col)[C], uint64_t meta, const SetTable& ta
         const int sbit = mask_bit(k, c);
         const bool ex = (full >> sbit) & 1;  // this lane's piece has this placement
         if (!TET_WAVE_ANY(ex)) continue;
+        const bool is_valid = (valid >> sbit) & 1;
+        const int my_row_all = row_all, my_row_valid = row_valid;
+        row_all += ex ? 1 : 0;
+        row_valid += is_valid ? 1 : 0;
         int a = 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
@@ -1003,7 +1013,7 @@ TET_HD void afterstates_env(const W (&col)[C], uint64_t meta, const SetTable& ta
         f[5] = (float)(sRT + drt - dlast);
         f[6] = 0.0f;
         f[7] = (float)(sF7 + df7);
-        emit(fast, k, c, f);
+        emit(fast, k, c, f, my_row_all, my_row_valid, is_valid);
         TET_SCHED_FENCE();  // one placement at a time: interleaving the unrolled columns only costs registers
       }
     }
@@ -1025,7 +1035,7 @@ TET_HD void afterstates_env(const W (&col)[C], uint64_t meta, const SetTable& ta
     heights_of<W, C>(fb, fh);
     float f[8];
     bcts_features<W, C, NCH, 12, true>(fb, fh, R, lut, aa, (int)((od >> 3) & 7u), eroded, kk, f);
-    emit(has, sk, sc, f);
+    emit(has, sk, sc, f, row_of_slot<C>(full, sk, sc), row_of_slot<C>(valid, sk, sc), ((valid >> sb) & 1) != 0);
   }
 }
 
@@ -1179,11 +1189,10 @@ TET_HD int rollout_env(const W (&col0)[C], uint64_t meta0, int a0, int length, i
         const uint64_t valid = meta_mask(meta);
         float best = 0.f;
         int best_row = -1;
-        afterstates_env<W, C, NCH>(col, meta, tab, hole_lut, R, [&](bool has, int sk, int sc, float (&f)[8]) {
+        afterstates_env<W, C, NCH>(col, meta, tab, hole_lut, R, [&](bool has, int, int, float (&f)[8], int, int row, bool is_valid) {
           if (!has) return;
-          if ((valid >> mask_bit(sk, sc)) & 1) {
+          if (is_valid) {
             const float v = fitness_of(f, w);
-            const int row = row_of_slot<C>(valid, sk, sc);
             if (best_row < 0 || v > best || (v == best && row < best_row)) {
               best = v;
               best_row = row;

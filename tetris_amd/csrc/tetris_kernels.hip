@@ -362,8 +362,11 @@ __global__ __launch_bounds__(BLK, (step_waves<W, CR>())) void step_kernel(const 
 #ifndef TET_STEP_GREEDY_WAVES
 #define TET_STEP_GREEDY_WAVES 4
 #endif
+#ifndef TET_AFTER_WAVES64
+#define TET_AFTER_WAVES64 2
+#endif
 template <typename W>
-constexpr int after_waves(int want) { return sizeof(W) == 4 ? want : (want > 2 ? 2 : want); }
+constexpr int after_waves(int want) { return sizeof(W) == 4 ? want : (want > TET_AFTER_WAVES64 ? TET_AFTER_WAVES64 : want); }
 
 struct StepManyParams {
   StepParams one;        // pointers of step 0; per-step outputs advance by B elements per step
@@ -410,11 +413,10 @@ __global__ __launch_bounds__(step_block<W>(), (POLICY == 0 ? step_waves<W, CR>()
         const uint64_t valid = tet::meta_mask(in.meta);
         float best = 0.f;
         int best_row = -1;
-        tet::afterstates_env<W, C, NCH>(in.col, in.meta, tab, hole_lut, cfg.R, [&](bool has, int sk, int sc, float (&f)[8]) {
+        tet::afterstates_env<W, C, NCH>(in.col, in.meta, tab, hole_lut, cfg.R, [&](bool has, int, int, float (&f)[8], int, int row, bool is_valid) {
           if (!has) return;
-          if ((valid >> tet::mask_bit(sk, sc)) & 1) {
+          if (is_valid) {
             const float v = tet::fitness_of(f, q.w);
-            const int row = tet::row_of_slot<C>(valid, sk, sc);
             if (best_row < 0 || v > best || (v == best && row < best_row)) {
               best = v;
               best_row = row;
@@ -616,7 +618,7 @@ __global__ __launch_bounds__(kBlock, (after_waves<W>(TET_AFTER_WAVES))) void aft
   const uint32_t env4 = (uint32_t)i * es4;
   const int nv = tet::popc(valid), na = tet::popc(full);
   float sink = 0.f;
-  tet::afterstates_env<W, C, NCH>(col, meta, tab, hole_lut, p.R, [&](bool has, int sk, int sc, float (&f)[8]) {
+  tet::afterstates_env<W, C, NCH>(col, meta, tab, hole_lut, p.R, [&](bool has, int sk, int sc, float (&f)[8], int row_all, int row_valid, bool is_valid) {
     has = has && live;
     if (TET_ABLATE & 64) {  // timing experiment: no feature stores
       if (has) sink += f[0] + f[1] + f[2] + f[3] + f[4] + f[5] + f[6] + f[7] + (float)(sk + sc);
@@ -626,21 +628,38 @@ __global__ __launch_bounds__(kBlock, (after_waves<W>(TET_AFTER_WAVES))) void aft
 #pragma unroll
       for (int q = 0; q < 8; ++q) f[q] *= p.direct_by[q];
     }
-    // the row of a placement follows the reference's enumeration order (tet::row_of_slot)
-    if (p.feats_all)
-      store_row_paired(p.feats_all, has, env4 + (uint32_t)tet::row_of_slot<C>(full, sk, sc) * rs4, f);
-    store_row_paired(p.feats, has && ((valid >> tet::mask_bit(sk, sc)) & 1),  // game.py:69
-                     env4 + (uint32_t)tet::row_of_slot<C>(valid, sk, sc) * rs4, f);
+    // the row of a placement follows the reference's enumeration order
+    if (p.feats_all) store_row_paired(p.feats_all, has, env4 + (uint32_t)row_all * rs4, f);
+    store_row_paired(p.feats, has && is_valid, env4 + (uint32_t)row_valid * rs4, f);  // game.py:69
   });
   if (TET_ABLATE & 64) {
     if (live) p.feats[i * p.env_stride] = sink;
     return;
   }
-  const float zero[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  for (int k = 0; k < p.a_max; ++k) {  // zero the rows past the last placement (wave-uniform loop)
-    const bool pad = live && k >= nv, pad_all = live && k >= na;
-    if (__ballot(pad) != 0ull) store_row_paired(p.feats, pad, env4 + (uint32_t)k * rs4, zero);
-    if (p.feats_all && __ballot(pad_all) != 0ull) store_row_paired(p.feats_all, pad_all, env4 + (uint32_t)k * rs4, zero);
+  // zero the rows past the last placement: the lanes of a pair write the two halves of one row per
+  // instruction as above, but there is nothing to exchange -- only the partner's base, count and liveness,
+  // fetched once
+  {
+    const bool odd = threadIdx.x & 1u;
+    const uint32_t part = odd ? 1u : 0u;
+    const uint32_t env4_o = swap_neighbour(env4);
+    const int nv_o = (int)swap_neighbour((uint32_t)(live ? nv : 0x7FFFFFFF)), na_o = (int)swap_neighbour((uint32_t)(live ? na : 0x7FFFFFFF));
+    const int nv_m = live ? nv : 0x7FFFFFFF, na_m = live ? na : 0x7FFFFFFF;
+    // rows of the pair's even / odd lane
+    const uint32_t base_e = odd ? env4_o : env4, base_o = odd ? env4 : env4_o;
+    const int nv_e = odd ? nv_o : nv_m, nv_od = odd ? nv_m : nv_o, na_e = odd ? na_o : na_m, na_od = odd ? na_m : na_o;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4* out = reinterpret_cast<float4*>(p.feats);
+    float4* out_all = reinterpret_cast<float4*>(p.feats_all);
+    for (int k = 0; k < p.a_max; ++k) {  // (wave-uniform loop)
+      const uint32_t r4 = (uint32_t)k * rs4 + part;
+      if (k >= nv_e) out[(size_t)base_e + r4] = z4;
+      if (k >= nv_od) out[(size_t)base_o + r4] = z4;
+      if (out_all) {
+        if (k >= na_e) out_all[(size_t)base_e + r4] = z4;
+        if (k >= na_od) out_all[(size_t)base_o + r4] = z4;
+      }
+    }
   }
   if (live) {
     p.n_valid[i] = (uint8_t)nv;
@@ -683,12 +702,11 @@ __global__ __launch_bounds__(kBlock, (after_waves<W>(TET_GREEDY_WAVES))) void gr
   float* fall = p.fitness_all ? p.fitness_all + i * (int64_t)p.a_max : nullptr;
   float best = 0.f;
   int best_row = -1;
-  tet::afterstates_env<W, C, NCH>(col, meta, tab, hole_lut, p.R, [&](bool has, int sk, int sc, float (&f)[8]) {
-          if (!has) return;
+  tet::afterstates_env<W, C, NCH>(col, meta, tab, hole_lut, p.R, [&](bool has, int, int, float (&f)[8], int row_all, int row, bool is_valid) {
+    if (!has) return;
     const float v = tet::fitness_of(f, p.w);
-    if (fall) fall[tet::row_of_slot<C>(full, sk, sc)] = v;
-    if ((valid >> tet::mask_bit(sk, sc)) & 1) {
-      const int row = tet::row_of_slot<C>(valid, sk, sc);
+    if (fall) fall[row_all] = v;
+    if (is_valid) {
       if (best_row < 0 || v > best || (v == best && row < best_row)) {
         best = v;
         best_row = row;
@@ -864,7 +882,7 @@ __global__ __launch_bounds__(kBlock) void encode_kernel(const int8_t* __restrict
 
 inline dim3 grid_for(int64_t B) { return dim3((unsigned)((B + kBlock - 1) / kBlock)); }
 inline dim3 rollout_grid(int64_t n) { return dim3((unsigned)((n + kRolloutBlock - 1) / kRolloutBlock)); }
-constexpr uint32_t kSmallBatch = 262144;
+constexpr uint32_t kSmallBatch = 65536;
 template <typename W>
 inline dim3 step_grid(int64_t B) { return dim3((unsigned)((B + step_block<W>() - 1) / step_block<W>())); }
 
@@ -895,8 +913,8 @@ struct LaunchStep {
     if (!packed_geometry<W>(p.cfg.R))
       hipLaunchKernelGGL((step_kernel<W, C, 0, 12>), step_grid<W>(p.B), dim3(step_block<W>()), 0, s, p);
     else if (p.cfg.R <= 10 * N && TET_LUT10) {
-      // small batches (at most 4 waves per SIMD): 256-env tiles put a workgroup on every CU from 65,536 envs
-      // on and shorten its table staging: 6.75 us against 7.24 us per step at 65,536 envs, 1 % slower at
+      // small batches (up to one wave per SIMD): 256-env tiles put a workgroup on every CU at 65,536 envs
+      // and shorten its table staging: 6.75 us against 7.24 us per step there; 5 % slower at 131,072 envs, 1 % at
       // 1 Mi envs and beyond (profiles/r03_experiments/small_batch_variants.txt)
       if (step_block<W>() > 256 && p.B <= kSmallBatch)
         hipLaunchKernelGGL((step_kernel<W, C, N, 10, 256>), dim3((p.B + 255) / 256), dim3(256), 0, s, p);
