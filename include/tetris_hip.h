@@ -46,7 +46,7 @@ extern "C" {
 #define TETRIS_HIP_ABI_VERSION 6
 
 #define TETRIS_MAX_PIECES 12
-#define TETRIS_MAX_COLUMNS 10
+#define TETRIS_MAX_COLUMNS 12
 #define TETRIS_N_CATALOGUE 9
 
 /* catalogue ids: class order of tetromino.py:33-576 */

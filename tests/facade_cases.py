@@ -215,18 +215,18 @@ def render_strings(device, golden_dir):
 
 
 def unsupported_widths_are_refused(device):
-    """game.py:21-28 accepts any num_columns; this build has kernels for 5..10 columns
+    """game.py:21-28 accepts any num_columns; this build has kernels for 5..12 columns
     and says so: the facade and the batched env raise TetrisHipError with the library's text, for widths on
     both sides of the range, before anything is allocated or launched."""
     import pytest
     from tetris_amd import Tetris, VecTetris
     from tetris_amd._lib import TetrisHipError
-    for C in (4, 11, 12, 16):
+    for C in (4, 13, 16, 40):
         with pytest.raises(TetrisHipError, match="num_columns not compiled into libtetris_hip"):
             Tetris(C, 20, device=device)
         with pytest.raises(TetrisHipError, match="num_columns not compiled into libtetris_hip"):
             VecTetris(C, 20, 8, device=device)
-    for C in (5, 10):  # the ends of the supported range work
+    for C in (5, 12):  # the ends of the supported range work
         env = Tetris(C, 12, device=device)
         fv, _ = env.get_after_states()
         assert fv.shape[0] > 0 and fv.shape[1] == 8

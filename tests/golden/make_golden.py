@@ -23,6 +23,7 @@ Fixture families:
                     global-RNG state after every call) and one-piece-set rollout
                     returns that pin the batched rollout kernel
   g8_render         print_board_to_string / State.__repr__ / piece reprs
+  g1_placements_12x20 / g10_traj_wide   boards of 11 and 12 columns (placements, seeded games)
   g9_rollouts_fed   single_rollout returns on MULTI-piece sets together with the list index the
                     reference's sampler handed out at every rollout step (the global bag advances
                     from rollout to rollout): the batched kernel replays them through its
@@ -152,10 +153,9 @@ def make_env(game, tetromino, C, R, piece_names, seed, feature_directions=None):
     return env
 
 
-def gen_trajectory(game, tetromino, C, R, piece_names, seed, n_steps, with_after):
+def gen_trajectory(game, tetromino, C, R, piece_names, seed, n_steps, with_after, A=40):
     env = make_env(game, tetromino, C, R, piece_names, seed)
     arng = np.random.default_rng(10_000 + seed)  # action stream, independent of np.random
-    A = 40
     rec = {k: [] for k in ("piece", "n_valid", "n_all", "action", "cols", "obs", "reward", "done", "lines",
                            "reset_after", "after_valid", "after_all")}
     first_piece = env.tetrominos.index(env.current_tetromino)
@@ -577,6 +577,20 @@ def gen_all_trajectories(game, tetromino):
             np.savez_compressed(os.path.join(HERE, f"g2_traj_{tag}_10x{R}.npz"), **trajs)
 
 
+def gen_wide(game, state, tetromino):
+    """Boards wider than the paper's ten columns (game.py:21-28 takes any width; the kernels are built for up to
+    twelve): placements of all nine pieces on 12x20 boards and seeded games on 12x20 / 11x24."""
+    np.savez_compressed(os.path.join(HERE, "g1_placements_12x20.npz"),
+                        **gen_placements(game, state, tetromino, 20, 12, 24, seed=5))
+    trajs = {}
+    for tag, names, C, R in (("default_12x20", None, 12, 20), ("standard7_11x24", STANDARD7, 11, 24)):
+        for seed in range(8):
+            tr = gen_trajectory(game, tetromino, C, R, names, seed, 200, with_after=(seed < 1), A=48)
+            for k, v in tr.items():
+                trajs[f"{tag}_s{seed}_{k}"] = v
+    np.savez_compressed(os.path.join(HERE, "g10_traj_wide.npz"), **trajs)
+
+
 def main():
     game, state, tetromino = import_reference()
     only = set(sys.argv[1:])  # e.g. `make_golden.py g7 g8` regenerates just those families
@@ -585,6 +599,8 @@ def main():
             gen_all_trajectories(game, tetromino)
         if "g7" in only:
             np.savez_compressed(os.path.join(HERE, "g7_rollouts.npz"), **gen_rollouts(game, tetromino))
+        if "g10" in only:
+            gen_wide(game, state, tetromino)
         if "g9" in only:
             np.savez_compressed(os.path.join(HERE, "g9_rollouts_fed.npz"), **gen_rollouts_fed(game, tetromino))
         if "g8" in only:
@@ -606,6 +622,7 @@ def main():
     from tetris import utils
     np.savez_compressed(os.path.join(HERE, "g8_render.npz"), **gen_render(game, state, tetromino, utils))
     np.savez_compressed(os.path.join(HERE, "g9_rollouts_fed.npz"), **gen_rollouts_fed(game, tetromino))
+    gen_wide(game, state, tetromino)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -135,11 +135,43 @@ def golden_trajectories_replay(device, orc, golden_dir):
         assert env.stats()["invalid"] == 0
 
 
+def golden_wide_trajectories(device, orc, golden_dir):
+    """g10: seeded reference games on 12x20 (default set) and 11x24 (seven pieces) boards, all seeds of a config
+    as one batch, pieces from the NumPy-exact device stream: every output of every step and the afterstate
+    matrices of seed 0."""
+    from tetris_amd import VecTetris
+    g = np.load(os.path.join(golden_dir, "g10_traj_wide.npz"))
+    for tag, pieces, C, R in (("default_12x20", "default", 12, 20), ("standard7_11x24", STANDARD7, 11, 24)):
+        S = 8
+        T = len(g[tag + "_s0_action"])
+        env = VecTetris(C, R, S, device=device, pieces=pieces, auto_reset=True, numpy_seeds=list(range(S)),
+                        stream_len=2 * T + 8)
+        for t in range(T):
+            np.testing.assert_array_equal(env.piece.cpu().numpy(), [g["%s_s%d_piece" % (tag, s)][t] for s in range(S)])
+            np.testing.assert_array_equal(env.n_valid.cpu().numpy(), [g["%s_s%d_n_valid" % (tag, s)][t] for s in range(S)])
+            if t < 60:
+                f, nv, fa, na = env.get_after_states(include_terminal=True)
+                np.testing.assert_array_equal(f[0].cpu().numpy(), g[tag + "_s0_after_valid"][t][:env.a_max])
+                np.testing.assert_array_equal(fa[0].cpu().numpy(), g[tag + "_s0_after_all"][t][:env.a_max])
+            act = np.array([g["%s_s%d_action" % (tag, s)][t] for s in range(S)], np.int32)
+            obs, rew, done, lines = env.step(torch.from_numpy(act))
+            obs, rew, done, lines = obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy(), lines.cpu().numpy()
+            cols = env.columns().cpu().numpy().astype(np.uint64).T
+            for s in range(S):
+                p = "%s_s%d_" % (tag, s)
+                np.testing.assert_array_equal(obs[s], g[p + "obs"][t])
+                assert int(rew[s]) == g[p + "reward"][t] and bool(done[s]) == bool(g[p + "done"][t])
+                assert int(lines[s]) == g[p + "lines"][t]
+                if not g[p + "done"][t]:
+                    np.testing.assert_array_equal(cols[s], g[p + "cols"][t])
+        env.check()
+
+
 def golden_placements_afterstates(device, orc, golden_dir):
     """g1 fixtures: every placement of all 9 pieces on hand-made boards, via set_boards + afterstates."""
     from tetris_amd import VecTetris
     from tetris_amd.tetromino import CATALOGUE
-    for name in ("g1_placements_10x20.npz", "g1_placements_10x40.npz", "g1_placements_6x10.npz"):
+    for name in ("g1_placements_10x20.npz", "g1_placements_10x40.npz", "g1_placements_6x10.npz", "g1_placements_12x20.npz"):
         g = np.load(os.path.join(golden_dir, name))
         R, C = int(g["R"]), int(g["C"])
         boards = g["boards"]
@@ -265,9 +297,14 @@ def edge_geometries(device, orc):
     for C, R, pieces, B in [(10, 4, "default", 130), (10, 27, "standard7", 65), (10, 28, "standard7", 63),
                             (10, 59, "default", 31), (6, 4, "standard7", 1), (8, 27, "default", 257),
                             (6, 59, "standard7", 64),
-                            # every column count the library is built for (5..10), odd ones included
+                            # every column count the library is built for (5..12), odd ones included
                             (5, 12, "standard7", 33), (5, 20, "default", 40), (7, 24, "standard7", 50),
                             (9, 20, "default", 70), (9, 40, "standard7", 30), (5, 30, "standard7", 20),
+                            # 11 and 12 columns: 12-bit level fields / 64-bit missing-cell words in the valid mask,
+                            # nine board planes, a_max = 44; both word sizes, packed and unpacked boards
+                            (11, 20, "default", 70), (12, 20, "standard7", 90), (12, 20, "default", 64),
+                            (11, 40, "standard7", 40), (12, 33, "default", 50), (12, 24, "standard7", 45),
+                            (12, 10, ["Straight", "ThreeLine", "Square"], 60),
                             # either side of every kernel-variant switch: 10-row / 12-row table chunks (R = 20 | 21),
                             # chunk borders inside the board (R = 10, 12, 13), compile-time chunk counts of the
                             # u64 kernels (stored rows 36 | 37 and 48 | 49)
@@ -474,7 +511,7 @@ def golden_placements_through_step(device, orc, golden_dir):
     observation against the fixture."""
     from tetris_amd import VecTetris
     from tetris_amd.tetromino import CATALOGUE
-    for fname in ("g1_placements_10x20.npz", "g1_placements_10x40.npz", "g1_placements_6x10.npz"):
+    for fname in ("g1_placements_10x20.npz", "g1_placements_10x40.npz", "g1_placements_6x10.npz", "g1_placements_12x20.npz"):
         g = np.load(os.path.join(golden_dir, fname))
         R, C = int(g["R"]), int(g["C"])
         term = g["terminal"].astype(bool)

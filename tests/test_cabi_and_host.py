@@ -40,7 +40,7 @@ def test_desc_init_and_argument_errors(hip_lib):
     assert hip_lib.desc_init(ctypes.byref(d), 10, 20, ids, 2, None) == 0
     assert (d.word_bytes, d.a_max, d.n_pieces) == (4, 36, 2)
     assert hip_lib.desc_init(ctypes.byref(d), 10, 40, ids, 2, None) == 0 and d.word_bytes == 8
-    assert hip_lib.desc_init(ctypes.byref(d), 11, 20, ids, 2, None) == -3     # TETRIS_E_COLUMNS (5..10 are built)
+    assert hip_lib.desc_init(ctypes.byref(d), 13, 20, ids, 2, None) == -3     # TETRIS_E_COLUMNS (5..12 are built)
     assert hip_lib.desc_init(ctypes.byref(d), 4, 20, ids, 2, None) == -3
     assert hip_lib.desc_init(ctypes.byref(d), 10, 3, ids, 2, None) == -4      # TETRIS_E_ROWS
     assert hip_lib.desc_init(ctypes.byref(d), 10, 20, ids, 0, None) == -5     # TETRIS_E_PIECES
@@ -56,7 +56,7 @@ def test_desc_init_and_argument_errors(hip_lib):
     assert "NULL" in hip_lib.error_string(-1)
     cols = (ctypes.c_int32 * 16)()
     n = hip_lib.supported_columns(cols, 16)
-    assert list(cols)[:n] == [5, 6, 7, 8, 9, 10]
+    assert list(cols)[:n] == [5, 6, 7, 8, 9, 10, 11, 12]
     from tetris_amd import build
     assert list(build._COLUMNS) == list(cols)[:n]  # the per-column translation units of the in-tree build
     assert hip_lib.status_words(1 << 20) == 4 * ((1 << 20) // 64)

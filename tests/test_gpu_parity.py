@@ -48,6 +48,8 @@ def test_tall_board_cfg5_properties():
 def test_mask_rescue_stress(orc):
     pc.mask_rescue_stress(DEV, orc, n_boards=1500)
     pc.mask_rescue_stress(DEV, orc, n_boards=500, R=40, seed=1)
+    pc.mask_rescue_stress(DEV, orc, n_boards=400, R=20, C=12, seed=3)  # 12-bit level fields, 64-bit missing-cell words
+    pc.mask_rescue_stress(DEV, orc, n_boards=200, R=40, C=11, seed=4)
 
 
 def test_facade_golden_trajectories(golden_dir):
@@ -217,3 +219,7 @@ def test_rollouts_fed_pieces(orc, golden_dir):
 def test_unsupported_widths_are_refused():
     import facade_cases as fc
     fc.unsupported_widths_are_refused(DEV)
+
+
+def test_golden_wide_trajectories(orc, golden_dir):
+    pc.golden_wide_trajectories(DEV, orc, golden_dir)

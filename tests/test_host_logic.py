@@ -39,6 +39,8 @@ def test_mask_rescue_stress(host_backend, orc):
     pc.mask_rescue_stress(DEV, orc, n_boards=600)
     pc.mask_rescue_stress(DEV, orc, n_boards=200, R=40, seed=1)
     pc.mask_rescue_stress(DEV, orc, n_boards=200, R=10, C=6, seed=2)
+    pc.mask_rescue_stress(DEV, orc, n_boards=250, R=20, C=12, seed=3)  # 12-bit level fields, 64-bit missing-cell words
+    pc.mask_rescue_stress(DEV, orc, n_boards=150, R=40, C=11, seed=4)
 
 
 def test_edge_geometries(host_backend, orc):
@@ -119,3 +121,7 @@ def test_gather_payload_from_the_step(host_backend):
 
 def test_rollouts_fed_pieces(host_backend, orc, golden_dir):
     pc.rollouts_fed_pieces(DEV, orc, golden_dir)
+
+
+def test_golden_wide_trajectories(host_backend, orc, golden_dir):
+    pc.golden_wide_trajectories(DEV, orc, golden_dir)

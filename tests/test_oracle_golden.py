@@ -13,7 +13,8 @@ def _load(golden_dir, name):
     return np.load(os.path.join(golden_dir, name))
 
 
-@pytest.mark.parametrize("name", ["g1_placements_10x20.npz", "g1_placements_10x40.npz", "g1_placements_6x10.npz"])
+@pytest.mark.parametrize("name", ["g1_placements_10x20.npz", "g1_placements_10x40.npz", "g1_placements_6x10.npz",
+                                  "g1_placements_12x20.npz"])
 def test_g1_placements(orc, golden_dir, name):
     """tetromino.py get_after_states + state.py clear/terminal/features, all 9 pieces."""
     g = _load(golden_dir, name)
@@ -147,3 +148,31 @@ def test_invalid_action_flag(orc):
     _, _, _, _, n_bad = env.step(a)
     assert n_bad == 3 and list(env.invalid) == [0, 1, 1, 1]
     np.testing.assert_array_equal(env.cells[1:], before[1:])
+
+
+@pytest.mark.parametrize("tag,names,C,R", [("default_12x20", "default", 12, 20), ("standard7_11x24", STANDARD7, 11, 24)])
+def test_g10_wide_trajectories(orc, golden_dir, tag, names, C, R):
+    """Seeded reference games on boards of 11 and 12 columns (game.py:21-28 takes any width)."""
+    g = _load(golden_dir, "g10_traj_wide.npz")
+    n_pieces = 2 if names == "default" else len(names)
+    done_total = 0
+    for seed in range(8):
+        p = "%s_s%d_" % (tag, seed)
+        T = len(g[p + "action"])
+        bag = orc.BagSampler(orc.NumpyLegacyRNG(seed), n_pieces)
+        stream = np.array([bag.next() for _ in range(1 + T + int(g[p + "done"].sum()))], np.uint8)[:, None]
+        env = orc.OracleVecEnv(C, R, 1, pieces=names, auto_reset=True, piece_stream=stream)
+        for t in range(T):
+            assert env.piece[0] == g[p + "piece"][t] and env.n_valid[0] == g[p + "n_valid"][t], (seed, t)
+            if (p + "after_valid") in g:
+                fv, nv, fa, na = env.afterstates(include_terminal=True)
+                A = fv.shape[1]
+                assert na[0] == g[p + "n_all"][t]
+                np.testing.assert_array_equal(fv[0], g[p + "after_valid"][t][:A])
+                np.testing.assert_array_equal(fa[0], g[p + "after_all"][t][:A])
+            obs, reward, done, lines, n_bad = env.step(np.array([g[p + "action"][t]]))
+            assert n_bad == 0
+            np.testing.assert_array_equal(obs[0], g[p + "obs"][t])
+            assert reward[0] == g[p + "reward"][t] and done[0] == g[p + "done"][t] and lines[0] == g[p + "lines"][t]
+            done_total += int(done[0])
+    assert done_total > 0

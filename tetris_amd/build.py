@@ -38,7 +38,7 @@ def is_stale():
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 
-_COLUMNS = (5, 6, 7, 8, 9, 10)  # == TET_COLUMNS in csrc/tetris_table.hpp (checked by the CPU tests)
+_COLUMNS = (5, 6, 7, 8, 9, 10, 11, 12)  # == TET_COLUMNS in csrc/tetris_table.hpp (checked by the CPU tests)
 _FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC"]
 
 

@@ -75,7 +75,7 @@
 namespace tet {
 
 constexpr int kMaxPieces = 12;   // pieces in one set (bag is 12 bits of meta)
-constexpr int kMaxCols = 10;     // 4*C slot bits fit the 48-bit mask; valid_mask packs 3 bits x C into 32
+constexpr int kMaxCols = 12;     // 4 x 12-bit mask fields fill the 48-bit valid mask
 constexpr int kNumCatalogue = 9;
 
 // ---- packed orientation descriptor --------------------------------------
@@ -695,9 +695,20 @@ TET_HD void bcts_features(const W (&col)[C], const int (&h)[C], int R, const uin
 //    be full (no stack cell sits at row >= R), so t <= 2.
 //  * e >= 2 can only be rescued when H = 4 (vertical Straight): rows R-2 and R-1 must
 //    both miss exactly column c (X_t & Y_t is that single column, or empty).
+// stride of the level fields of valid_mask's level word: 10 bits up to ten columns (the paper's boards: the
+// shifts below then stay in the range the round-1/2 kernels were tuned on), 12 bits for 11 and 12 columns
+TET_HD constexpr int level_stride(int C) { return C <= 10 ? 10 : 12; }
+template <int C> struct MissBits { typedef uint32_t type; };   // 3 bits per column: 32 bits up to 10 columns,
+template <> struct MissBits<11> { typedef uint64_t type; };    // 64 beyond
+template <> struct MissBits<12> { typedef uint64_t type; };
+TET_HD int ctz_any(uint32_t x) { return __builtin_ctz(x); }
+TET_HD int ctz_any(uint64_t x) { return __builtin_ctzll(x); }
+
 template <typename W, int C>
 TET_HD uint64_t valid_mask(const W (&col)[C], const int (&h)[C], const OrientEntry* tab, uint64_t fullmask, int R) {
-  static_assert(C <= 10, "missing-cell rows are packed 3 bits per column into 32 bits; 10-bit level fields");
+  static_assert(C <= 12, "four 12-bit level fields + one empty field fill the 64-bit level word; 12-bit mask fields");
+  constexpr int LS = level_stride(C);
+  typedef typename MissBits<C>::type FT;
   uint32_t P[3] = {0u, 0u, 0u};
 #pragma unroll
   for (int c = 0; c < C; ++c) P[c >> 2] |= (uint32_t)h[c] << (8 * (c & 3));
@@ -712,8 +723,8 @@ TET_HD uint64_t valid_mask(const W (&col)[C], const int (&h)[C], const OrientEnt
       g |= ((((P[q] + K) & 0x80808080u) * 0x00204081u) >> 28) << (4 * q);  // gather the four bit-7s
     lv[l - 1] = g;
   }
-  const uint64_t Z = ((uint64_t)lv[0] << 10) | ((uint64_t)lv[1] << 20) | ((uint64_t)lv[2] << 30) |
-                     ((uint64_t)lv[3] << 40);
+  const uint64_t Z = ((uint64_t)lv[0] << LS) | ((uint64_t)lv[1] << (2 * LS)) | ((uint64_t)lv[2] << (3 * LS)) |
+                     ((uint64_t)lv[3] << (4 * LS));
   // A placement that pokes above row R - 1 is rescued only by a row among R-3 .. R-1 that the piece
   // completes, i.e. one that misses at most four cells.  A cell in row R-3 or above means h >= R - 2
   // (level set 3), so when fewer than C - 4 columns reach that height no such row exists: the whole
@@ -723,15 +734,17 @@ TET_HD uint64_t valid_mask(const W (&col)[C], const int (&h)[C], const OrientEnt
   uint32_t X[3] = {0u, 0u, 0u}, Y[3] = {0u, 0u, 0u};
   uint32_t rv1 = 0, rv2 = 0;
   if (rescue) {
-    uint32_t Fall = 0;
+    FT Fall = 0;
 #pragma unroll
-    for (int c = 0; c < C; ++c) Fall |= ((uint32_t)(col[c] >> (R - 3)) & 7u) << (3 * c);  // cells of rows R-3..R-1
-    const uint32_t Mall = ~Fall;  // missing cells, 3 bits per column
+    for (int c = 0; c < C; ++c) Fall |= (FT)((uint32_t)(col[c] >> (R - 3)) & 7u) << (3 * c);  // cells of rows R-3..R-1
+    const FT Mall = (FT)~Fall;  // missing cells, 3 bits per column
+    constexpr FT kEveryThird = (FT)0x9249249249249249ull & (FT)(((FT)1 << (3 * C)) - 1);  // bit 3c
+    constexpr FT kTop = (FT)1 << (8 * sizeof(FT) - 1);
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
-      const uint32_t m = (Mall >> t) & (0x09249249u & ((1u << (3 * C)) - 1u));  // bit 3c: column c misses row R-3+t
-      const int lo = (__builtin_ctz(m | 0x80000000u) * 11) >> 5;                // / 3
-      const int hi = ((31 - __builtin_clz(m | 1u)) * 11) >> 5;
+      const FT m = (FT)(Mall >> t) & kEveryThird;                     // bit 3c: column c misses row R-3+t
+      const int lo = (ctz_any((FT)(m | kTop)) * 11) >> 5;              // / 3
+      const int hi = ((bitlen((FT)(m | 1)) - 1) * 11) >> 5;            // (bitlen: the top bit of m is never set)
       X[t] = ~0u << hi;
       Y[t] = m ? (2u << lo) - 1u : 0u;  // a full row (only on boards that were set from outside) rescues nothing
     }
@@ -747,7 +760,7 @@ TET_HD uint64_t valid_mask(const W (&col)[C], const int (&h)[C], const OrientEnt
     uint32_t r = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) r |= (uint32_t)(Z >> e.sh[j]);
-    const uint32_t i1 = r >> 10, i2 = r;
+    const uint32_t i1 = r >> LS, i2 = r;
     uint32_t v = ~i1;
     if (rescue) {
       // rescue by one cleared row (e = 1)
@@ -959,7 +972,7 @@ TET_HD void afterstates_env(const W (&col)[C], uint64_t meta, const SetTable& ta
         for (int j = 0; j < 4; ++j) {
           constexpr int kz = 0;
           const int i = c + j < C ? c + j : kz;
-          if (c + j < C) {
+          if (c + j < C && j < wu) {  // (wave-uniform: no piece in this wavefront reaches further right)
             const int bj = (int)((dsc >> (6 + 5 * j)) & 3u), nj = (int)((dsc >> (8 + 5 * j)) & 7u);  // nj = 0 beyond the piece
             const int bot = (j < wd) ? a + bj : h[i];
             const int g = bot - h[i];  // cells left empty under the piece in this column
@@ -972,12 +985,17 @@ TET_HD void afterstates_env(const W (&col)[C], uint64_t meta, const SetTable& ta
             df7 += ((int)(D[i] & 31u) + top) * nj;
             NHN[j + 1] = (int)((D[i] >> 5) & 63u) + g;
             if (c + j == C - 1) dlast = nj;  // the right wall's term counts the cells of the last column
-            F &= XN[j + 1];
+          } else if (c + j < C) {  // an unchanged column of the window
+            XN[j + 1] = col[i];
+            HN[j + 1] = h[i];
+            NHN[j + 1] = (int)((D[i] >> 5) & 63u);
+            hrows |= HO[i];
           } else {
             XN[j + 1] = wall;
             HN[j + 1] = R;
             NHN[j + 1] = 0;
           }
+          F &= XN[j + 1];
         }
         F &= (W)((W)~(W)0 << a);  // rows of the piece only (see clear_lines)
         const bool fast = ex && F == 0;

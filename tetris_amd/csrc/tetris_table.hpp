@@ -56,14 +56,15 @@ inline int n_placements(int pid, int C) {
 }
 
 // thresholds: footprint column j needs slack R - h >= need_j = H - b_j.  valid_mask keeps the
-// column sets B_l = {c : slack < l} in 10-bit fields of one 64-bit word (level l at bit 10 l); the
-// shift 10*(need_j - 1) + j lines column c + j of level need_j up with bit 10 + c and of level
-// need_j - 1 with bit c.
-inline void pack_mask_fields(const CatOrient& o, OrientEntry* e) {
+// column sets B_l = {c : slack < l} in LS-bit fields of one 64-bit word (level l at bit LS l, LS =
+// tet::level_stride(C): 10 up to ten columns, else 12); the shift LS (need_j - 1) + j lines column c + j
+// of level need_j up with bit LS + c and of level need_j - 1 with bit c.
+inline void pack_mask_fields(const CatOrient& o, OrientEntry* e, int C) {
+  const int LS = level_stride(C);
   int H = 0;
   for (int j = 0; j < o.w; ++j)
     if (o.b[j] + o.n[j] > H) H = o.b[j] + o.n[j];
-  for (int j = 0; j < o.w; ++j) e->sh[j] = (uint32_t)(10 * (H - o.b[j] - 1) + j);
+  for (int j = 0; j < o.w; ++j) e->sh[j] = (uint32_t)(LS * (H - o.b[j] - 1) + j);
   for (int j = o.w; j < 4; ++j) e->sh[j] = e->sh[0];  // absent columns repeat column 0's term (OR is idempotent)
   e->vert4 = (o.w == 1 && H == 4) ? ~0u : 0u;
   for (int t = 1; t < 3; ++t) {  // board row R-3+t holds piece row rho when the anchor is R+1-H
@@ -92,7 +93,7 @@ inline void build_table(const TetrisDesc* d, SetTable* t) {
       for (int oi = 0; oi < p.n_orient[l]; ++oi) {
         OrientEntry* e = &t->orient[i][l * 2 + oi];
         e->desc = pack_orient(p.o[l][oi]);
-        pack_mask_fields(p.o[l][oi], e);
+        pack_mask_fields(p.o[l][oi], e, C);
         for (int c = 0; c + p.o[l][oi].w <= C; ++c) full |= 1ull << mask_bit(2 * l + oi, c);
       }
     t->fullmask[i] = full;
@@ -102,9 +103,10 @@ inline void build_table(const TetrisDesc* d, SetTable* t) {
 // num_columns values the kernels are instantiated for (one place for the
 // library, the dispatch switch and the CPU test harness)
 // (5 is the lower bound: with 4 columns a horizontal Straight IS a full row wherever it lands, even in the
-// overflow rows, which the bit-parallel valid mask does not model; 10 the upper one, see valid_mask)
+// overflow rows, which the bit-parallel valid mask does not model; 12 the upper one: four 12-bit fields
+// are the 48-bit valid mask of the control word, see valid_mask)
 #ifndef TET_COLUMNS  // (experiment builds narrow this: -D'TET_COLUMNS(X)=X(10)')
-#define TET_COLUMNS(X) X(5) X(6) X(7) X(8) X(9) X(10)
+#define TET_COLUMNS(X) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12)
 #endif
 
 inline bool columns_supported(int C) {
