@@ -1,9 +1,10 @@
 // tetris_kernels.hip -- gfx950 kernels + the C-ABI of include/tetris_hip.h.
 //
-// One lane per env; column bitboards in plane-major (SoA) HBM layout so that a
-// wave64 reads/writes 256 contiguous bytes (u32) or 512 (u64) per column plane.
-// No dense contraction anywhere -> no MFMA; the path is HBM-streaming integer
-// bit work (popcount / clz / shifts) with the per-set piece table staged in LDS.
+// One lane per env; column bitboards in tile-major HBM storage (tet::plane_index: the planes of a
+// wavefront's 64 envs back to back, one contiguous record per wave; 256 contiguous bytes (u32) or 512
+// (u64) per plane and wave).  No dense contraction anywhere -> no MFMA; the path is integer bit work
+// (popcount / clz / shifts / byte-table reads from LDS) over state streamed from HBM, and it is bound by
+// vector-instruction issue, not by bytes.
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 #include <string.h>
