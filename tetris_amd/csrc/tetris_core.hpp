@@ -972,7 +972,10 @@ TET_HD void afterstates_env(const W (&col)[C], uint64_t meta, const SetTable& ta
         for (int j = 0; j < 4; ++j) {
           constexpr int kz = 0;
           const int i = c + j < C ? c + j : kz;
-          if (c + j < C && j < wu) {  // (wave-uniform: no piece in this wavefront reaches further right)
+          if (c + j < C) {
+            // (all four window columns, also beyond the widest footprint of the wavefront: bounding this loop by
+            // the wave-uniform width saves 4 % of the vector instructions and costs the stepping kernels 8-30 %
+            // -- more scalar branches, worse register allocation at 128 VGPRs; measured, round 3)
             const int bj = (int)((dsc >> (6 + 5 * j)) & 3u), nj = (int)((dsc >> (8 + 5 * j)) & 7u);  // nj = 0 beyond the piece
             const int bot = (j < wd) ? a + bj : h[i];
             const int g = bot - h[i];  // cells left empty under the piece in this column
@@ -985,11 +988,6 @@ TET_HD void afterstates_env(const W (&col)[C], uint64_t meta, const SetTable& ta
             df7 += ((int)(D[i] & 31u) + top) * nj;
             NHN[j + 1] = (int)((D[i] >> 5) & 63u) + g;
             if (c + j == C - 1) dlast = nj;  // the right wall's term counts the cells of the last column
-          } else if (c + j < C) {  // an unchanged column of the window
-            XN[j + 1] = col[i];
-            HN[j + 1] = h[i];
-            NHN[j + 1] = (int)((D[i] >> 5) & 63u);
-            hrows |= HO[i];
           } else {
             XN[j + 1] = wall;
             HN[j + 1] = R;
