@@ -24,6 +24,9 @@
 #ifndef TET_ABLATE
 #define TET_ABLATE 0
 #endif
+#ifndef TET_BAG_SMALL_PATH
+#define TET_BAG_SMALL_PATH 1   // 0: always the three-group search of the bag draw (A/B timing)
+#endif
 #ifndef TET_RESCUE_SKIP
 #define TET_RESCUE_SKIP 1   // 0: valid_mask always evaluates the rescue by cleared rows (A/B timing)
 #endif
@@ -309,6 +312,14 @@ TET_HD int bag_draw(uint32_t& bag, int n_pieces, uint32_t r16) {
 // the same draw through the nibble select table (LutLayout::kSelNib)
 TET_HD int bag_draw_lut(uint32_t& bag, int n_pieces, uint32_t r16, const uint8_t* sel_nib) {
   if (bag == 0) bag = (1u << n_pieces) - 1u;
+#if TET_BAG_SMALL_PATH
+  if (n_pieces <= 4) {  // (uniform over the launch) the whole bag is one nibble: no group search
+    const int k4 = scale16(r16, popc(bag));
+    const int pos4 = (int)sel_nib[bag * 4u + (uint32_t)k4];
+    bag &= ~(1u << pos4);
+    return pos4;
+  }
+#endif
   int k = scale16(r16, popc(bag));
   const int c0 = popc(bag & 0xFu), c1 = c0 + popc(bag & 0xF0u);
   const int grp = (k >= c0) + (k >= c1);
