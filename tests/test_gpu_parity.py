@@ -179,6 +179,22 @@ def test_cfg5_full_size_bit_exact(orc):
     pc.cfg3_full_size_bit_exact(DEV, orc, R=40, steps=24, board_every=12)
 
 
+def test_afterstate_family_full_size(orc):
+    """get_after_states (both matrices) and get_best_policy of EVERY env of 262,144-env batches, whole-array
+    bit-exact against the oracle, in steady-state play: 10x20 (u32 boards) and 10x40 (u64 boards)."""
+    pc.afterstate_family_full_size(DEV, orc, B=1 << 18, R=20, steps=24, every=8)
+    pc.afterstate_family_full_size(DEV, orc, B=1 << 18, R=40, pieces="standard7", steps=40, every=20)
+
+
+@pytest.mark.parametrize("C", [5, 6, 7, 8, 9, 10, 11, 12])
+def test_repeat_and_shard_consistency(C):
+    """Every kernel of the afterstate family, 196,608 envs (several workgroups per compute unit): repeated
+    launches agree bit for bit, the whole batch equals its 16,384-env shards, two copies stepping with the
+    in-kernel greedy policy stay identical -- 32-bit and 64-bit boards, both piece sets."""
+    for R, pieces in ((20, "default"), (20, "standard7"), (40, "default"), (40, "standard7")):
+        pc.repeat_and_shard_consistency(DEV, C=C, R=R, pieces=pieces)
+
+
 def test_bench_rccl_path_one_rank():
     """bench.py as the driver starts it, but with the collective path forced on in a world of ONE rank
     (TETRIS_BENCH_FORCE_DIST=1): process-group set-up over RCCL, the barrier, the bitmask all-gather on

@@ -55,6 +55,12 @@ def test_greedy_policy(host_backend, orc, golden_dir):
     pc.greedy_policy(DEV, orc, golden_dir)
 
 
+def test_afterstate_family_whole_batch(host_backend, orc):
+    pc.afterstate_family_full_size(DEV, orc, B=1500, steps=40, every=8)
+    pc.afterstate_family_full_size(DEV, orc, B=700, R=40, pieces="standard7", steps=60, every=20)
+    pc.afterstate_family_full_size(DEV, orc, B=500, R=20, C=12, steps=40, every=10)
+
+
 def test_rollouts(host_backend, orc):
     pc.rollouts(DEV, orc)
 

@@ -935,6 +935,11 @@ TET_HD void afterstates_env(const W (&col)[C], uint64_t meta, const SetTable& ta
                     (TET_WAVE_ANY((d0 & 7u) > 3) ? 1 : 0);
     const int wu1 = 1 + (TET_WAVE_ANY((d1 & 7u) > 1) ? 1 : 0) + (TET_WAVE_ANY((d1 & 7u) > 2) ? 1 : 0) +
                     (TET_WAVE_ANY((d1 & 7u) > 3) ? 1 : 0);
+    // the two 12-bit fields of this loop, as 32-bit words: every per-placement test below is then a
+    // constant-position bit test (no 64-bit variable shifts in the walk)
+    const uint32_t fe0 = mask_field<C>(full, 2 * L), fe1 = mask_field<C>(full, 2 * L + 1);
+    const uint32_t fv0 = mask_field<C>(valid, 2 * L), fv1 = mask_field<C>(valid, 2 * L + 1);
+    uint32_t sl0 = 0, sl1 = 0;  // placements of this loop that clear lines
 #pragma unroll
     for (int c = 0; c < C; ++c) {
       // AND of the columns / OR of the hole masks outside the window c .. c+3 (shared by both orientations)
@@ -952,10 +957,9 @@ TET_HD void afterstates_env(const W (&col)[C], uint64_t meta, const SetTable& ta
         const uint32_t dsc = oi ? d1 : d0;
         const int wu = oi ? wu1 : wu0;  // wave-uniform
         const int wd = (int)(dsc & 7u), H = (int)((dsc >> 3) & 7u);
-        const int sbit = mask_bit(k, c);
-        const bool ex = (full >> sbit) & 1;  // this lane's piece has this placement
+        const bool ex = ((oi ? fe1 : fe0) >> c) & 1u;  // this lane's piece has this placement
         if (!TET_WAVE_ANY(ex)) continue;
-        const bool is_valid = (valid >> sbit) & 1;
+        const bool is_valid = ((oi ? fv1 : fv0) >> c) & 1u;
         const int my_row_all = row_all, my_row_valid = row_valid;
         row_all += ex ? 1 : 0;
         row_valid += is_valid ? 1 : 0;
@@ -1008,7 +1012,7 @@ TET_HD void afterstates_env(const W (&col)[C], uint64_t meta, const SetTable& ta
         }
         F &= (W)((W)~(W)0 << a);  // rows of the piece only (see clear_lines)
         const bool fast = ex && F == 0;
-        if (ex && F != 0) slow |= 1ull << sbit;
+        if (ex && F != 0) (oi ? sl1 : sl0) |= 1u << c;
         if (!TET_WAVE_ANY(fast)) continue;
         // row transitions of columns c .. c+wu (the left neighbour of c+wu may have changed)
         int drt = 0;
@@ -1044,6 +1048,7 @@ TET_HD void afterstates_env(const W (&col)[C], uint64_t meta, const SetTable& ta
         TET_SCHED_FENCE();  // one placement at a time: interleaving the unrolled columns only costs registers
       }
     }
+    slow |= ((uint64_t)sl0 << mask_bit(2 * L, 0)) | ((uint64_t)sl1 << mask_bit(2 * L + 1, 0));
   }
   while (TET_WAVE_ANY(slow != 0) && !(TET_ABLATE & 256)) {  // line-clearing placements (rare): full evaluation, state.py:33 onwards
     const bool has = slow != 0;  // lanes that are done keep pace on placement 0 (it always exists)

@@ -366,8 +366,16 @@ __global__ __launch_bounds__(BLK, (step_waves<W, CR>())) void step_kernel(const 
 #ifndef TET_AFTER_WAVES64
 #define TET_AFTER_WAVES64 2
 #endif
-template <typename W>
-constexpr int after_waves(int want) { return sizeof(W) == 4 ? want : (want > TET_AFTER_WAVES64 ? TET_AFTER_WAVES64 : want); }
+// 64-bit boards of 11 and 12 columns: ONE wave per SIMD (up to 512 registers, nothing in scratch, one
+// workgroup per compute unit).  Built for two, get_best_policy of these boards returned wrong fitness
+// values in workgroups that started on a compute unit where another one was already resident -- every
+// launch, never in the first workgroup of a compute unit, never with one workgroup per compute unit;
+// DESIGN.md section 3.2 "open issue" has what was measured and what was ruled out.  The net for it is
+// tests/parity_cases.repeat_and_shard_consistency (every width, both word sizes, in the -m gpu suite).
+template <typename W, int C>
+constexpr int after_waves(int want) {
+  return sizeof(W) == 4 ? want : (C >= 11 ? 1 : (want > TET_AFTER_WAVES64 ? TET_AFTER_WAVES64 : want));
+}
 
 struct StepManyParams {
   StepParams one;        // pointers of step 0; per-step outputs advance by B elements per step
@@ -383,7 +391,7 @@ struct StepManyParams {
 // step's outputs are written to trajectory buffers [K][B]...; bit-identical to K launches of
 // step_kernel with step_idx0, step_idx0 + 1, ...  (the per-step keys are re-derived on device).
 template <typename W, int C, int NCH, int POLICY, int CR>
-__global__ __launch_bounds__(step_block<W>(), (POLICY == 0 ? step_waves<W, CR>() : after_waves<W>(TET_STEP_GREEDY_WAVES))) void step_many_kernel(const StepManyParams q) {
+__global__ __launch_bounds__(step_block<W>(), (POLICY == 0 ? step_waves<W, CR>() : after_waves<W, C>(TET_STEP_GREEDY_WAVES))) void step_many_kernel(const StepManyParams q) {
   static_assert(POLICY == 0 || CR == 12, "the greedy policy evaluates terminal afterstates too: 12-row chunks");
   constexpr int kBlock = step_block<W>();  // shadows the file-wide tile size inside this kernel
   const StepParams& p = q.one;
@@ -596,7 +604,7 @@ __device__ __forceinline__ void store_row_paired(float* base, bool has, uint32_t
 }
 
 template <typename W, int C, int NCH>
-__global__ __launch_bounds__(kBlock, (after_waves<W>(TET_AFTER_WAVES))) void afterstates_kernel(const AfterParams p) {
+__global__ __launch_bounds__(kBlock, (after_waves<W, C>(TET_AFTER_WAVES))) void afterstates_kernel(const AfterParams p) {
   __shared__ SetTable tab;
   __shared__ __attribute__((aligned(16))) uint8_t hole_lut[tet::kAfterLutBytes];
   stage_after_lut(hole_lut);
@@ -686,7 +694,7 @@ struct GreedyParams {
 // placement (raw order, terminal included, like game.py:103) and the best NON-terminal action.
 // The [B][a_max][8] feature matrix never touches HBM.
 template <typename W, int C, int NCH>
-__global__ __launch_bounds__(kBlock, (after_waves<W>(TET_GREEDY_WAVES))) void greedy_kernel(const GreedyParams p) {
+__global__ __launch_bounds__(kBlock, (after_waves<W, C>(TET_GREEDY_WAVES))) void greedy_kernel(const GreedyParams p) {
   __shared__ SetTable tab;
   __shared__ __attribute__((aligned(16))) uint8_t hole_lut[tet::kAfterLutBytes];
   stage_after_lut(hole_lut);
@@ -743,7 +751,7 @@ struct RolloutParams {
 // 512 lanes per workgroup: with the 35 KiB of afterstate tables two workgroups = 16 waves fit a CU
 constexpr int kRolloutBlock = 512;
 template <typename W, int C, int NCH>
-__global__ __launch_bounds__(kRolloutBlock, (after_waves<W>(TET_STEP_GREEDY_WAVES))) void rollouts_kernel(const RolloutParams p) {
+__global__ __launch_bounds__(kRolloutBlock, (after_waves<W, C>(TET_STEP_GREEDY_WAVES))) void rollouts_kernel(const RolloutParams p) {
   constexpr int kBlock = kRolloutBlock;  // shadows the file-wide tile size inside this kernel
   __shared__ StepLds<W, C, kBlock, 12, true> lds;
   SetTable& tab = lds.tab;

@@ -21,3 +21,13 @@ for name, kw in (("config 3: 10x20, default pieces, 256 steps", dict(steps=256, 
     eps = pc.cfg3_full_size_bit_exact("cuda", orc, B=1 << 20, board_every=16, **kw)
     print("%s: 1,048,576 envs bit-exact on obs / reward / done / lines / n_valid / piece / action every step and the "
           "boards every 16 steps; %d episodes finished; %.0f s" % (name, eps, time.perf_counter() - t0), flush=True)
+
+for name, kw in (("10x20, default pieces", dict(R=20, pieces="default", steps=160, every=32)),
+                 ("10x40, default pieces", dict(R=40, pieces="default", steps=192, every=64)),
+                 ("10x20, standard-7 pieces", dict(R=20, pieces="standard7", steps=96, every=32)),
+                 ("12x20, default pieces", dict(R=20, C=12, pieces="default", steps=128, every=64))):
+    t0 = time.perf_counter()
+    n = pc.afterstate_family_full_size("cuda", orc, B=1 << 20, **kw)
+    print("afterstate family, %s: get_after_states (valid + include-terminal matrices) and get_best_policy of all "
+          "1,048,576 envs bit-exact at %d points of steady-state play; %.0f s" % (name, n, time.perf_counter() - t0),
+          flush=True)
