@@ -190,8 +190,9 @@ def test_afterstate_family_full_size(orc):
 def test_repeat_and_shard_consistency(C):
     """Every kernel of the afterstate family, 196,608 envs (several workgroups per compute unit): repeated
     launches agree bit for bit, the whole batch equals its 16,384-env shards, two copies stepping with the
-    in-kernel greedy policy stay identical -- 32-bit and 64-bit boards, both piece sets."""
-    for R, pieces in ((20, "default"), (20, "standard7"), (40, "default"), (40, "standard7")):
+    in-kernel greedy policy stay identical -- 32-bit and 64-bit boards, packed (x20, x40) and one plane per column
+    (x24, x50: the NCH = 0 kernel variants), both piece sets."""
+    for R, pieces in ((20, "default"), (20, "standard7"), (40, "default"), (40, "standard7"), (24, "default"), (50, "standard7")):
         pc.repeat_and_shard_consistency(DEV, C=C, R=R, pieces=pieces)
 
 

@@ -931,10 +931,11 @@ TET_HD void afterstates_env(const W (&col)[C], uint64_t meta, const SetTable& ta
     const uint32_t d0 = tab.orient[piece][2 * L].desc, d1 = tab.orient[piece][2 * L + 1].desc;
     if (!TET_WAVE_ANY((d0 | d1) >> 31)) continue;
     // widest footprint of each orientation over the wave: narrower pieces skip the extra columns
-    const int wu0 = 1 + (TET_WAVE_ANY((d0 & 7u) > 1) ? 1 : 0) + (TET_WAVE_ANY((d0 & 7u) > 2) ? 1 : 0) +
+    const int wu0_ = 1 + (TET_WAVE_ANY((d0 & 7u) > 1) ? 1 : 0) + (TET_WAVE_ANY((d0 & 7u) > 2) ? 1 : 0) +
                     (TET_WAVE_ANY((d0 & 7u) > 3) ? 1 : 0);
-    const int wu1 = 1 + (TET_WAVE_ANY((d1 & 7u) > 1) ? 1 : 0) + (TET_WAVE_ANY((d1 & 7u) > 2) ? 1 : 0) +
+    const int wu1_ = 1 + (TET_WAVE_ANY((d1 & 7u) > 1) ? 1 : 0) + (TET_WAVE_ANY((d1 & 7u) > 2) ? 1 : 0) +
                     (TET_WAVE_ANY((d1 & 7u) > 3) ? 1 : 0);
+    const int wu0 = (TET_ABLATE & 1024) ? 4 : wu0_, wu1 = (TET_ABLATE & 1024) ? 4 : wu1_;
     // the two 12-bit fields of this loop, as 32-bit words: every per-placement test below is then a
     // constant-position bit test (no 64-bit variable shifts in the walk)
     const uint32_t fe0 = mask_field<C>(full, 2 * L), fe1 = mask_field<C>(full, 2 * L + 1);
@@ -958,7 +959,7 @@ TET_HD void afterstates_env(const W (&col)[C], uint64_t meta, const SetTable& ta
         const int wu = oi ? wu1 : wu0;  // wave-uniform
         const int wd = (int)(dsc & 7u), H = (int)((dsc >> 3) & 7u);
         const bool ex = ((oi ? fe1 : fe0) >> c) & 1u;  // this lane's piece has this placement
-        if (!TET_WAVE_ANY(ex)) continue;
+        if (!(TET_ABLATE & 512) && !TET_WAVE_ANY(ex)) continue;
         const bool is_valid = ((oi ? fv1 : fv0) >> c) & 1u;
         const int my_row_all = row_all, my_row_valid = row_valid;
         row_all += ex ? 1 : 0;
@@ -1013,7 +1014,7 @@ TET_HD void afterstates_env(const W (&col)[C], uint64_t meta, const SetTable& ta
         F &= (W)((W)~(W)0 << a);  // rows of the piece only (see clear_lines)
         const bool fast = ex && F == 0;
         if (ex && F != 0) (oi ? sl1 : sl0) |= 1u << c;
-        if (!TET_WAVE_ANY(fast)) continue;
+        if (!(TET_ABLATE & 512) && !TET_WAVE_ANY(fast)) continue;
         // row transitions of columns c .. c+wu (the left neighbour of c+wu may have changed)
         int drt = 0;
 #pragma unroll

@@ -372,9 +372,12 @@ __global__ __launch_bounds__(BLK, (step_waves<W, CR>())) void step_kernel(const 
 // launch, never in the first workgroup of a compute unit, never with one workgroup per compute unit;
 // DESIGN.md section 3.2 "open issue" has what was measured and what was ruled out.  The net for it is
 // tests/parity_cases.repeat_and_shard_consistency (every width, both word sizes, in the -m gpu suite).
+#ifndef TET_AFTER_WAVES64_WIDE
+#define TET_AFTER_WAVES64_WIDE 1  // (2 reproduces the fault: tools/stress_consistency.py)
+#endif
 template <typename W, int C>
 constexpr int after_waves(int want) {
-  return sizeof(W) == 4 ? want : (C >= 11 ? 1 : (want > TET_AFTER_WAVES64 ? TET_AFTER_WAVES64 : want));
+  return sizeof(W) == 4 ? want : (C >= 11 ? TET_AFTER_WAVES64_WIDE : (want > TET_AFTER_WAVES64 ? TET_AFTER_WAVES64 : want));
 }
 
 struct StepManyParams {
@@ -714,7 +717,7 @@ __global__ __launch_bounds__(kBlock, (after_waves<W, C>(TET_GREEDY_WAVES))) void
   tet::afterstates_env<W, C, NCH>(col, meta, tab, hole_lut, p.R, [&](bool has, int, int, float (&f)[8], int row_all, int row, bool is_valid) {
     if (!has) return;
     const float v = tet::fitness_of(f, p.w);
-    if (fall) fall[row_all] = v;
+    if (fall && !(TET_ABLATE & 2048)) fall[row_all] = v;
     if (is_valid) {
       if (best_row < 0 || v > best || (v == best && row < best_row)) {
         best = v;

@@ -19,7 +19,7 @@ if len(sys.argv) > 1:
 print("source hash of the library:", _lib.load().source_hash())
 runs = int(os.environ.get("STRESS_RUNS", "1"))
 configs = [(C, R, pieces) for C in [int(x) for x in os.environ.get("STRESS_C", "5 6 7 8 9 10 11 12").split()]
-           for R, pieces in ((20, "default"), (20, "standard7"), (40, "default"))]
+           for R, pieces in ((20, "default"), (20, "standard7"), (40, "default"), (24, "default"), (50, "default"))]
 fails = {c: [] for c in configs}
 t0 = time.perf_counter()
 for run in range(runs):
