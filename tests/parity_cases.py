@@ -853,60 +853,11 @@ def afterstate_family_full_size(device, orc, B=1 << 18, R=20, C=10, pieces="defa
     return checks
 
 
-def repeat_and_shard_consistency(device, C=12, R=20, pieces="default", B=3 << 16, warm=30, shard=1 << 14, repeats=3,
-                                 rollouts=True):
-    """Every kernel of the afterstate family on a batch large enough that several workgroups share a
-    compute unit: (a) repeated launches on the same state must agree bit for bit, (b) the whole-batch
-    result must equal the same boards evaluated in shards of `shard` envs (one workgroup per compute
-    unit), (c) two copies of the env stepping with the in-kernel greedy policy must stay identical.
-    No oracle: this is the net for timing-dependent faults (round 3 found one in the 12-column
-    get_best_policy kernel that only showed when two workgroups were resident on a compute unit)."""
-    from tetris_amd import VecTetris
-    env = VecTetris(C, R, B, device=device, pieces=pieces, auto_reset=True, seed=5)
-    for t in range(warm):
-        env.step()
-    snap = env.state_dict()
-
-    def greedy():
-        ba, bv, fit = env.greedy_actions(include_fitness=True)
-        return ba.clone(), bv.clone(), fit.clone()
-
-    def matrix():
-        f, nv, fa, na = env.get_after_states(include_terminal=True)
-        return f.clone(), nv.clone(), fa.clone(), na.clone()
-
-    g0, m0 = greedy(), matrix()
-    for rep in range(repeats - 1):
-        for a, b in zip(greedy(), g0):
-            assert torch.equal(a.view(torch.int32), b.view(torch.int32)), "get_best_policy differs between launches (rep %d)" % rep
-        for a, b in zip(matrix(), m0):
-            assert torch.equal(a, b), "get_after_states differs between launches (rep %d)" % rep
-    if rollouts:
-        r0 = env.rollouts(length=3, n=2, policy="greedy").clone()
-        r1 = env.rollouts(length=3, n=2, policy="greedy")
-        assert torch.equal(r0.view(torch.int64), r1.view(torch.int64)), "rollouts differ between launches"
-    # (b) shards
-    cells = env.boards()
-    piece = env.piece.to(torch.int64)
-    for lo in range(0, B, shard):
-        n = min(shard, B - lo)
-        e2 = VecTetris(C, R, n, device=device, pieces=pieces)
-        e2.set_boards(cells[lo:lo + n], piece=piece[lo:lo + n])
-        ba, bv, fit = e2.greedy_actions(include_fitness=True)
-        assert torch.equal(ba, g0[0][lo:lo + n]), "best action: whole batch != shard at env %d" % lo
-        assert torch.equal(fit.view(torch.int32), g0[2][lo:lo + n].view(torch.int32)), "fitness: whole batch != shard at env %d" % lo
-        f, nv, fa, na = e2.get_after_states(include_terminal=True)
-        assert torch.equal(fa, m0[2][lo:lo + n]) and torch.equal(f, m0[0][lo:lo + n]) and torch.equal(nv, m0[1][lo:lo + n])
-    # (c) two copies under the in-kernel greedy policy
-    twin = VecTetris(C, R, B, device=device, pieces=pieces, auto_reset=True, seed=5)
-    twin.load_state_dict(snap)
-    env.load_state_dict(snap)
-    o1 = env.step_many(6, policy="greedy")
-    o2 = twin.step_many(6, policy="greedy")
-    for k in ("obs", "reward", "_done", "lines", "action", "n_valid", "piece"):
-        assert torch.equal(o1[k], o2[k]), "step_many(greedy): %s differs between two copies" % k
-    assert torch.equal(env.cols, twin.cols) and torch.equal(env.meta, twin.meta)
-    return True
+def repeat_and_shard_consistency(device, **kw):
+    """tetris_amd.selftest.afterstate_family_consistency (the shipped self-test): repeated launches agree,
+    whole batch == shards, twin envs under the in-kernel greedy policy stay identical."""
+    from tetris_amd import selftest
+    return selftest.afterstate_family_consistency(device, **kw)
 
 
 def numpy_exact_bag_stream(device, orc, golden_dir):

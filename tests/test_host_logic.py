@@ -61,6 +61,12 @@ def test_afterstate_family_whole_batch(host_backend, orc):
     pc.afterstate_family_full_size(DEV, orc, B=500, R=20, C=12, steps=40, every=10)
 
 
+def test_selftest_runs_on_the_harness(host_backend):
+    from tetris_amd import selftest
+    assert selftest.run([(12, 20, "default"), (7, 40, "standard7"), (10, 24, "default")], device=DEV, verbose=False,
+                        B=700, shard=256, warm=12) == []
+
+
 def test_rollouts(host_backend, orc):
     pc.rollouts(DEV, orc)
 

@@ -371,7 +371,7 @@ __global__ __launch_bounds__(BLK, (step_waves<W, CR>())) void step_kernel(const 
 // values in workgroups that started on a compute unit where another one was already resident -- every
 // launch, never in the first workgroup of a compute unit, never with one workgroup per compute unit;
 // DESIGN.md section 3.2 "open issue" has what was measured and what was ruled out.  The net for it is
-// tests/parity_cases.repeat_and_shard_consistency (every width, both word sizes, in the -m gpu suite).
+// tetris_amd/selftest.py (every width, both word sizes; in the -m gpu suite and in smoke()).
 #ifndef TET_AFTER_WAVES64_WIDE
 #define TET_AFTER_WAVES64_WIDE 1  // (2 reproduces the fault: tools/stress_consistency.py)
 #endif
