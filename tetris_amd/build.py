@@ -42,15 +42,99 @@ _COLUMNS = (5, 6, 7, 8, 9, 10, 11, 12)  # == TET_COLUMNS in csrc/tetris_table.hp
 _FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC"]
 
 
+_LLVM = os.environ.get("TETRIS_LLVM_BIN", "/opt/rocm/lib/llvm/bin")
+_SHIFT64 = ("v_lshlrev_b64", "v_lshrrev_b64", "v_ashrrev_i64")
+_VGPR_GRANULE = 8
+
+
+def _regs(tok):
+    import re
+    out = set()
+    for a, b, c in re.findall(r"\bv\[(\d+):(\d+)\]|\bv(\d+)\b", tok):
+        if c:
+            out.add(int(c))
+        else:
+            out.update(range(int(a), int(b) + 1))
+    return out
+
+
+def patch_last_vgpr_shifts(asm):
+    """gfx950: a 64-bit shift (v_lshlrev_b64 / v_lshrrev_b64 / v_ashrrev_i64) whose 32-bit shift amount is
+    the LAST vector register of the wave's allocation shifts by (v0 & 63) instead whenever another wave shares
+    the SIMD (tools/ubench/shift64_last_vgpr.hip; found in round 3 through wrong get_best_policy results that
+    only showed with two workgroups on a compute unit).  hipcc (ROCm 7.2) hands that register out like any
+    other and offers no way to reserve it, so the device assembly is patched before it is assembled: the amount
+    is moved to the low half of the destination pair first (or, when the shift is in place, swapped through
+    v0).  Returns (patched text, number of instructions patched)."""
+    import re
+    lines = asm.split("\n")
+    # kernel symbol -> last allocated VGPR, from the descriptor that follows each kernel's code
+    last = {}
+    for m in re.finditer(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", asm, re.S):
+        n = re.search(r"\.amdhsa_next_free_vgpr (\d+)", m.group(2))
+        a = re.search(r"\.amdhsa_accum_offset (\d+)", m.group(2))
+        if n:
+            arch = min(int(n.group(1)), int(a.group(1))) if a else int(n.group(1))
+            last[m.group(1)] = ((arch + _VGPR_GRANULE - 1) // _VGPR_GRANULE) * _VGPR_GRANULE - 1
+    out, cur, patched = [], None, 0
+    pat = re.compile(r"^(\s*)(%s)\s+(v\[(\d+):(\d+)\]),\s*v(\d+),\s*(.+?)\s*$" % "|".join(_SHIFT64))
+    for ln in lines:
+        lab = re.match(r"^(\S+):", ln)
+        if lab and lab.group(1) in last:
+            cur = lab.group(1)
+        m = pat.match(ln.split(";")[0]) if cur else None
+        if m and int(m.group(6)) == last[cur]:
+            ind, op, dst, dlo, dhi, amt, srcv = m.group(1), m.group(2), m.group(3), int(m.group(4)), int(m.group(5)), int(m.group(6)), m.group(7)
+            src_regs = _regs(srcv)
+            if not ({dlo, dhi} & src_regs) and amt not in (dlo, dhi):
+                out.append("%sv_mov_b32_e32 v%d, v%d ; (shift amount out of the last allocated VGPR: tetris_amd/build.py)" % (ind, dlo, amt))
+                out.append("%s%s %s, v%d, %s" % (ind, op, dst, dlo, srcv))
+            elif 0 not in ({dlo, dhi} | src_regs) and amt != 0:
+                out.append("%sv_swap_b32 v0, v%d ; (shift amount out of the last allocated VGPR: tetris_amd/build.py)" % (ind, amt))
+                out.append("%s%s %s, v0, %s" % (ind, op, dst, srcv))
+                out.append("%sv_swap_b32 v0, v%d" % (ind, amt))
+            else:
+                raise RuntimeError("cannot patch '%s' in %s" % (ln.strip(), cur))
+            patched += 1
+            continue
+        out.append(ln)
+    return "\n".join(out), patched
+
+
+def _compile_unit(hipcc, src, name, defs, d, verbose):
+    """One translation unit -> host object with the (patched) device code embedded:
+    device assembly, hazard patch, assemble, link the code object, bundle, host compile."""
+    asm, obj, co, fb, host = (os.path.join(d, name + e) for e in (".s", ".dev.o", ".co", ".hipfb", ".o"))
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd, stderr=None if verbose else subprocess.DEVNULL)
+
+    run([hipcc] + _FLAGS + defs + ["-S", "--cuda-device-only", src, "-o", asm])
+    with open(asm) as f:
+        text, n = patch_last_vgpr_shifts(f.read())
+    with open(asm, "w") as f:
+        f.write(text)
+    run([_LLVM + "/clang", "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c", asm, "-o", obj])
+    run([_LLVM + "/lld", "-flavor", "gnu", "-m", "elf64_amdgpu", "--no-undefined", "-shared", obj, "-o", co])
+    run([_LLVM + "/clang-offload-bundler", "-type=o", "-bundle-align=4096",
+         "-targets=host-x86_64-unknown-linux-gnu,hipv4-amdgcn-amd-amdhsa--gfx950", "-input=/dev/null", "-input=" + co, "-output=" + fb])
+    run([hipcc] + _FLAGS + defs + ["--cuda-host-only", "-Xclang", "-fcuda-include-gpubinary", "-Xclang", fb, "-c", src, "-o", host])
+    return host, n
+
+
 def build_hip(force=False, verbose=False, jobs=None):
     """Compile the HIP kernels + C-ABI for gfx950 into tetris_amd/csrc/libtetris_hip.so.
 
     The kernels are templates on the column count; the source is compiled once per column count
-    (-DTET_PART=<C>) plus once as the main unit (-DTET_SPLIT_MAIN, the C-ABI), in parallel hipcc
-    processes, and the objects are linked (see "translation units" in tetris_kernels.hip)."""
+    (-DTET_PART=<C>) plus once as the main unit (-DTET_SPLIT_MAIN, the C-ABI), in parallel, and the objects
+    are linked (see "translation units" in tetris_kernels.hip).  Every unit goes through its device assembly
+    so that patch_last_vgpr_shifts can run on it."""
     if not force and not is_stale():
         return SO_PATH
     import tempfile
+    from concurrent.futures import ThreadPoolExecutor
     hipcc = _hipcc()
     src = os.path.join(_CSRC, "tetris_kernels.hip")
     jobs = jobs or max(1, min(len(_COLUMNS) + 1, (os.cpu_count() or 2)))
@@ -58,33 +142,12 @@ def build_hip(force=False, verbose=False, jobs=None):
     with tempfile.TemporaryDirectory(prefix="tetris_build_") as d:
         units = [("main", ["-DTET_SPLIT_MAIN", '-DTET_SRC_HASH="%s"' % source_hash()])] + \
                 [("c%d" % c, ["-DTET_PART=%d" % c]) for c in _COLUMNS]
-        objs, running = [], []
-        pending = list(units)
-
-        def reap(block):
-            for pr, name in list(running):
-                if pr.poll() is None and not block:
-                    continue
-                if pr.wait() != 0:
-                    for other, _ in running:
-                        if other.poll() is None:
-                            other.kill()
-                    raise subprocess.CalledProcessError(pr.returncode, "hipcc -c (%s)" % name)
-                running.remove((pr, name))
-                if block:
-                    return
-
-        while pending or running:
-            while pending and len(running) < jobs:
-                name, defs = pending.pop(0)
-                obj = os.path.join(d, name + ".o")
-                cmd = [hipcc] + _FLAGS + defs + ["-c", src, "-o", obj]
-                if verbose:
-                    print(" ".join(cmd))
-                running.append((subprocess.Popen(cmd), name))
-                objs.append(obj)
-            if running:
-                reap(block=True)
+        with ThreadPoolExecutor(max_workers=jobs) as pool:
+            results = list(pool.map(lambda u: _compile_unit(hipcc, src, u[0], u[1], d, verbose), units))
+        objs = [r[0] for r in results]
+        n_patched = sum(r[1] for r in results)
+        if verbose or n_patched:
+            print("tetris_amd.build: %d 64-bit shift(s) moved off the last allocated VGPR" % n_patched)
         try:
             cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", tmp]
             if verbose:

@@ -366,18 +366,20 @@ __global__ __launch_bounds__(BLK, (step_waves<W, CR>())) void step_kernel(const 
 #ifndef TET_AFTER_WAVES64
 #define TET_AFTER_WAVES64 2
 #endif
-// 64-bit boards of 11 and 12 columns: ONE wave per SIMD (up to 512 registers, nothing in scratch, one
-// workgroup per compute unit).  Built for two, get_best_policy of these boards returned wrong fitness
-// values in workgroups that started on a compute unit where another one was already resident -- every
-// launch, never in the first workgroup of a compute unit, never with one workgroup per compute unit;
-// DESIGN.md section 3.2 "open issue" has what was measured and what was ruled out.  The net for it is
-// tetris_amd/selftest.py (every width, both word sizes; in the -m gpu suite and in smoke()).
-#ifndef TET_AFTER_WAVES64_WIDE
-#define TET_AFTER_WAVES64_WIDE 1  // (2 reproduces the fault: tools/stress_consistency.py)
-#endif
+// A hardware hazard met on the way (round 3): on gfx950 a 64-bit shift -- v_lshlrev_b64, v_lshrrev_b64,
+// v_ashrrev_i64 -- whose 32-bit shift amount sits in the LAST vector register of the wave's allocation (v255
+// of 256, v167 of 168, v127 of 128) shifts by (v0 & 63) instead whenever another wave shares the SIMD
+// (tools/ubench/shift64_last_vgpr.hip: 0 wrong results at one workgroup per compute unit, 4-5 % at eight;
+// v_lshlrev_b32, v_mad_u64_u32, v_lshl_add_u64 are not affected).  The kernels of this family fill their
+// register budgets, all multiples of the allocation granule, so hipcc (ROCm 7.2) did place shift amounts there:
+// get_best_policy / get_after_states / rollouts results were wrong only where two workgroups shared a compute
+// unit.  Nothing in the source can keep the allocator off that register (amdgpu_num_vgpr has no effect on these
+// kernels), so tetris_amd/build.py patches the device ASSEMBLY of every translation unit before it is assembled
+// (patch_last_vgpr_shifts), and tools/check_last_vgpr.py -- run by the CPU tests on the built library --
+// disassembles it and fails if one kernel still has the pattern.  DESIGN.md section 3.2.
 template <typename W, int C>
 constexpr int after_waves(int want) {
-  return sizeof(W) == 4 ? want : (C >= 11 ? TET_AFTER_WAVES64_WIDE : (want > TET_AFTER_WAVES64 ? TET_AFTER_WAVES64 : want));
+  return sizeof(W) == 4 ? want : (want > TET_AFTER_WAVES64 ? TET_AFTER_WAVES64 : want);
 }
 
 struct StepManyParams {
