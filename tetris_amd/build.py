@@ -124,6 +124,18 @@ def _compile_unit(hipcc, src, name, defs, d, verbose):
     return host, n
 
 
+def build_variant(out_path, extra_flags=(), verbose=False):
+    """An experiment build of the whole source as ONE translation unit with extra flags (tools/ablate.py,
+    tools/asm_variant.py: e.g. -DTET_ABLATE=..., -D'TET_COLUMNS(X)=X(10)'), through the same assembly pipeline as
+    the product -- a variant library must not differ from it by an unpatched hardware hazard."""
+    import tempfile
+    with tempfile.TemporaryDirectory(prefix="tetris_variant_") as d:
+        host, n = _compile_unit(_hipcc(), os.path.join(_CSRC, "tetris_kernels.hip"), "variant",
+                                list(extra_flags) + ['-DTET_SRC_HASH="%s"' % source_hash()], d, verbose)
+        subprocess.check_call([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", host, "-o", out_path])
+    return out_path, n
+
+
 def build_hip(force=False, verbose=False, jobs=None):
     """Compile the HIP kernels + C-ABI for gfx950 into tetris_amd/csrc/libtetris_hip.so.
 

@@ -1219,7 +1219,6 @@ TET_HD int rollout_env(const W (&col0)[C], uint64_t meta0, int a0, int length, i
         use_policy = true;
         action = -1;
       } else {  // greedy: first non-terminal action of maximal fitness (game.py:102-120 on valid ones)
-        const uint64_t valid = meta_mask(meta);
         float best = 0.f;
         int best_row = -1;
         afterstates_env<W, C, NCH>(col, meta, tab, hole_lut, R, [&](bool has, int, int, float (&f)[8], int, int row, bool is_valid) {

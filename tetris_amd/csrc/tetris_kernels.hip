@@ -424,7 +424,6 @@ __global__ __launch_bounds__(step_block<W>(), (POLICY == 0 ? step_waves<W, CR>()
       int action = -1;
       bool use_policy = true;
       if (POLICY == 1) {  // greedy: first non-terminal action of maximal fitness
-        const uint64_t valid = tet::meta_mask(in.meta);
         float best = 0.f;
         int best_row = -1;
         tet::afterstates_env<W, C, NCH>(in.col, in.meta, tab, hole_lut, cfg.R, [&](bool has, int, int, float (&f)[8], int, int row, bool is_valid) {

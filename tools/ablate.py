@@ -34,18 +34,18 @@ newest_src = max(os.path.getmtime(f) for f in glob.glob(os.path.join(os.path.dir
                  glob.glob(os.path.join(os.path.dirname(src), "*.inc")))
 vdir = os.path.join(ROOT, "build_variants")
 os.makedirs(vdir, exist_ok=True)
-procs = []
+from concurrent.futures import ThreadPoolExecutor  # noqa: E402
+todo = []
 for m in masks:
     out = os.path.join(vdir, "libtetris_abl_%d.so" % m)
     if os.path.exists(out) and os.environ.get("ABL_REBUILD") != "1" and os.path.getmtime(out) > newest_src:
         continue
-    procs.append(subprocess.Popen(
-        [build._hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC"] +
-        (["-DTET_ABLATE=%d" % (m % 1000), "-DTET_STEP_WAVES=%d" % (m // 1000)] if m not in per_mask_flags else []) +
-        extra + per_mask_flags.get(m, []) + [src, "-o", out]))
-for pr in procs:
-    if pr.wait() != 0:
-        sys.exit("variant build failed")
+    flags = (["-DTET_ABLATE=%d" % (m % 1000), "-DTET_STEP_WAVES=%d" % (m // 1000)] if m not in per_mask_flags else []) + \
+        extra + per_mask_flags.get(m, [])
+    todo.append((out, flags))
+# (through the product's assembly pipeline: tetris_amd.build.build_variant, incl. the 64-bit-shift hazard patch)
+with ThreadPoolExecutor(max_workers=max(1, min(8, len(todo) or 1))) as pool:
+    list(pool.map(lambda t: build.build_variant(t[0], t[1]), todo))
 if os.environ.get("ABL_COMPILE_ONLY") == "1":
     sys.exit(0)
 libs = {m: _lib._Binding(ctypes.CDLL(os.path.join(vdir, "libtetris_abl_%d.so" % m))) for m in masks}

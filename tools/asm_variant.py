@@ -4,7 +4,9 @@
    asm_variant.py count <kernel-substring>
    asm_variant.py nops <name> <kernel-substring> <first> <last> [pad]
         s_nop <pad> after every instruction with index first..last of that kernel -> build_variants/libasm_<name>.so
-Used to bisect the co-residency fault by instruction range."""
+Used to bisect the co-residency fault by instruction range.  NOTE: these variants are assembled from
+the compiler's UNPATCHED assembly on purpose (the product and tools/ablate.py go through
+tetris_amd.build.patch_last_vgpr_shifts)."""
 import os
 import re
 import subprocess
