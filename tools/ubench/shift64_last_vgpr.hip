@@ -85,6 +85,42 @@ void run(const char* name, int wgs, int iters) {
   (void)hipFree(d);
 }
 
+// Other allocation sizes: the amount in v167 of a 168-register kernel, v127 of 128, and v250 of a kernel that uses
+// 251 registers (256 allocated: v250 is NOT the last allocated one).
+#define PROBE_REG(NAME, REG, BOUNDS)                                                                              \
+  __global__ __launch_bounds__(256, BOUNDS) void NAME(uint32_t* wrong, uint32_t* as_v0, int iters) {             \
+    uint32_t bad = 0, like_v0 = 0;                                                                                \
+    uint32_t seed = threadIdx.x * 2654435761u + blockIdx.x * 40503u + 1;                                          \
+    for (int it = 0; it < iters; ++it) {                                                                          \
+      seed = seed * 1664525u + 1013904223u;                                                                       \
+      const uint32_t amt = (seed >> 9) & 31;                                                                      \
+      uint64_t r;                                                                                                 \
+      uint32_t v0now;                                                                                             \
+      asm volatile("v_mov_b32 " REG ", %2\n\ts_nop 4\n\tv_lshlrev_b64 %0, " REG ", 1\n\tv_mov_b32 %1, v0"       \
+                   : "=&v"(r), "=&v"(v0now) : "v"(amt) : REG);                                                    \
+      bad += r != (1ull << amt);                                                                                  \
+      like_v0 += r != (1ull << amt) && r == (1ull << (v0now & 63));                                               \
+    }                                                                                                             \
+    if (bad) atomicAdd(wrong, bad);                                                                               \
+    if (like_v0) atomicAdd(as_v0, like_v0);                                                                       \
+  }
+PROBE_REG(probe_v167, "v167", 3)
+PROBE_REG(probe_v127, "v127", 4)
+PROBE_REG(probe_v250, "v250", 2)
+
+template <typename K>
+void run3(const char* name, K kernel, int wgs, int iters) {
+  uint32_t* d;
+  (void)hipMalloc(&d, 8);
+  (void)hipMemset(d, 0, 8);
+  hipLaunchKernelGGL(kernel, dim3(wgs), dim3(256), 0, 0, d, d + 1, iters);
+  (void)hipDeviceSynchronize();
+  uint32_t h[2] = {0, 0};
+  (void)hipMemcpy(h, d, 8, hipMemcpyDeviceToHost);
+  printf("%-50s %5d workgroups, %6d per lane: %u wrong results (%u of them = 1 << (v0 & 63))\n", name, wgs, iters, h[0], h[1]);
+  (void)hipFree(d);
+}
+
 template <int MODE>
 void run2(const char* name, int wgs, int iters) {
   uint32_t* d;
@@ -108,5 +144,8 @@ int main() {
   run2<2>("v_mad_u64_u32, first factor in v255", 2048, 2000);
   run2<3>("v_mad_u64_u32, second factor in v255", 2048, 2000);
   run2<4>("v_lshl_add_u64, shift amount in v255", 2048, 2000);
+  run3("v_lshlrev_b64, amount in v167 of 168 registers", probe_v167, 3072, 2000);
+  run3("v_lshlrev_b64, amount in v127 of 128 registers", probe_v127, 4096, 2000);
+  run3("v_lshlrev_b64, amount in v250 of 251 (256 allocated)", probe_v250, 2048, 2000);
   return 0;
 }
