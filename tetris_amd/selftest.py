@@ -43,18 +43,26 @@ def afterstate_family_consistency(device="cuda", C=10, R=20, pieces="default", B
         r0 = env.rollouts(length=3, n=2, policy="greedy").clone()
         r1 = env.rollouts(length=3, n=2, policy="greedy")
         assert torch.equal(r0.view(torch.int64), r1.view(torch.int64)), "rollouts differ between launches"
-    # (b) shards
-    cells = env.boards()
-    piece = env.piece.to(torch.int64)
+    # (b) shards: exact copies of the state of `shard` envs (same seed, env offset and step index, so the rollouts
+    # draw the same pieces), one workgroup per compute unit
+    assert shard % 64 == 0
     for lo in range(0, B, shard):
         n = min(shard, B - lo)
-        e2 = VecTetris(C, R, n, device=device, pieces=pieces)
-        e2.set_boards(cells[lo:lo + n], piece=piece[lo:lo + n])
+        e2 = VecTetris(C, R, n, device=device, pieces=pieces, auto_reset=True, seed=5, env_offset=lo)
+        e2.cols.copy_(env.cols[lo // 64:(lo + n + 63) // 64])
+        e2.meta.copy_(env.meta[lo:lo + n])
+        e2.piece.copy_(env.piece[lo:lo + n])
+        e2.n_valid.copy_(env.n_valid[lo:lo + n])
+        e2.step_idx = env.step_idx
         ba, bv, fit = e2.greedy_actions(include_fitness=True)
         assert torch.equal(ba, g0[0][lo:lo + n]), "best action: whole batch != shard at env %d" % lo
         assert torch.equal(fit.view(torch.int32), g0[2][lo:lo + n].view(torch.int32)), "fitness: whole batch != shard at env %d" % lo
         f, nv, fa, na = e2.get_after_states(include_terminal=True)
-        assert torch.equal(fa, m0[2][lo:lo + n]) and torch.equal(f, m0[0][lo:lo + n]) and torch.equal(nv, m0[1][lo:lo + n])
+        assert torch.equal(fa, m0[2][lo:lo + n]) and torch.equal(f, m0[0][lo:lo + n]) and torch.equal(nv, m0[1][lo:lo + n]), \
+            "get_after_states: whole batch != shard at env %d" % lo
+        if rollouts:
+            r2 = e2.rollouts(length=3, n=2, policy="greedy")
+            assert torch.equal(r2.view(torch.int64), r0[lo:lo + n].view(torch.int64)), "rollouts: whole batch != shard at env %d" % lo
     # (c) two copies under the in-kernel greedy policy
     twin = VecTetris(C, R, B, device=device, pieces=pieces, auto_reset=True, seed=5)
     twin.load_state_dict(snap)
