@@ -383,12 +383,12 @@ def greedy_policy(device, orc, golden_dir, B=400):
             np.testing.assert_array_equal(f, g[tag + "_fitness"][t][:k].astype(np.float32))
 
 
-def rollouts(device, orc, B=96):
+def rollouts(device, orc, B=96, geometries=((10, "default", 20, 5), (10, "standard7", 12, 6))):
     """tetris_hip_rollouts (game.py:129-160 fan-out) vs the oracle, both policies, mid-game boards."""
     from tetris_amd import VecTetris
-    for pieces, R, seed in (("default", 20, 5), ("standard7", 12, 6)):
-        env = VecTetris(10, R, B, device=device, pieces=pieces, auto_reset=False, seed=seed)
-        ref = orc.OracleVecEnv(10, R, B, pieces=pieces, auto_reset=False, seed=seed, nthreads=0)
+    for C, pieces, R, seed in geometries:
+        env = VecTetris(C, R, B, device=device, pieces=pieces, auto_reset=False, seed=seed)
+        ref = orc.OracleVecEnv(C, R, B, pieces=pieces, auto_reset=False, seed=seed, nthreads=0)
         for t in range(int(R * 1.6)):  # play towards the top so that rollouts do die
             env.step()
             ref.step()

@@ -196,6 +196,12 @@ def test_repeat_and_shard_consistency(C):
         pc.repeat_and_shard_consistency(DEV, C=C, R=R, pieces=pieces)
 
 
+def test_rollouts_many_workgroups_per_compute_unit(orc):
+    """perform_rollouts against the oracle on batches whose (env, action) lanes put several workgroups on every
+    compute unit -- 32- and 64-bit boards, incl. the 9-column 64-bit kernel that had the last-VGPR hazard."""
+    pc.rollouts(DEV, orc, B=12288, geometries=((10, "default", 20, 5), (9, "default", 40, 7), (12, "standard7", 40, 8)))
+
+
 def test_bench_rccl_path_one_rank():
     """bench.py as the driver starts it, but with the collective path forced on in a world of ONE rank
     (TETRIS_BENCH_FORCE_DIST=1): process-group set-up over RCCL, the barrier, the bitmask all-gather on
